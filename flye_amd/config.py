@@ -1,0 +1,66 @@
+"""Per-read-type parameter presets reaching the overlap hot path.
+
+Values restate the reference's shipped config files (flat ``key = float`` text,
+reference ``src/common/config.h:36-72``); every value is stored as a float32
+exactly like ``Config::_parameters`` (``config.h:69,100``):
+
+* ``flye/config/bin_cfg/asm_raw_reads.cfg:8-32``   -> ``raw``
+* ``flye/config/bin_cfg/asm_corrected_reads.cfg``  -> ``corrected``
+* ``flye/config/bin_cfg/asm_hifi.cfg:8-32``        -> ``hifi``
+* ``flye/config/bin_cfg/asm_subasm.cfg``           -> ``subasm``
+* ``flye/config/bin_cfg/asm_defaults.cfg:5``       -> ``meta_read_filter_kmer_freq``
+
+``tests/test_config.py`` re-parses the real files when /root/reference is
+present and checks these tables against them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_COMMON = {
+    "meta_read_filter_kmer_freq": 100,
+    "repeat_kmer_rate": 100,
+    "maximum_jump": 1500,
+}
+
+PRESETS = {
+    "raw": dict(_COMMON, kmer_size=17, use_minimizers=0, minimizer_window=0,
+                reads_base_alignment=0, assemble_kmer_sample=1,
+                meta_read_top_kmer_rate=0.40, maximum_overhang=1500,
+                assemble_ovlp_divergence=0.10, assemble_divergence_relative=1,
+                hpc_scoring_on=0),
+    "corrected": dict(_COMMON, kmer_size=17, use_minimizers=1, minimizer_window=5,
+                      reads_base_alignment=1, assemble_kmer_sample=2,
+                      meta_read_top_kmer_rate=0.75, maximum_overhang=500,
+                      assemble_ovlp_divergence=0.03, assemble_divergence_relative=0,
+                      hpc_scoring_on=0),
+    "hifi": dict(_COMMON, kmer_size=17, use_minimizers=1, minimizer_window=10,
+                 reads_base_alignment=1, assemble_kmer_sample=2,
+                 meta_read_top_kmer_rate=0.75, maximum_overhang=500,
+                 assemble_ovlp_divergence=0.01, assemble_divergence_relative=0,
+                 hpc_scoring_on=1),
+    "subasm": dict(_COMMON, kmer_size=31, use_minimizers=1, minimizer_window=10,
+                   reads_base_alignment=1, assemble_kmer_sample=2,
+                   meta_read_top_kmer_rate=0.75, maximum_jump=500, maximum_overhang=100,
+                   assemble_ovlp_divergence=0.02, assemble_divergence_relative=0,
+                   hpc_scoring_on=0),
+}
+
+# constants of the assemble stage (reference src/assemble/main_assemble.cpp)
+MIN_FREQ = 2            # :207
+DETECTOR_MIN_OVERLAP = 1000  # :174, :231 -- always 1000 in `assemble`
+
+CFG_FILES = {"raw": "asm_raw_reads.cfg", "corrected": "asm_corrected_reads.cfg",
+             "hifi": "asm_hifi.cfg", "subasm": "asm_subasm.cfg"}
+
+
+def preset(name: str) -> dict:
+    """Preset with every value rounded through float32 like Config::get()."""
+    return {k: float(np.float32(v)) for k, v in PRESETS[name].items()}
+
+
+def params_string(name: str) -> str:
+    """``key=value,...`` form accepted by the reference's ``Config::addParameters``
+    (``config.h:84-96``) -- used to drive oracle/_ref/ref_dumper without cfg files."""
+    return ",".join(f"{k}={v!r}" if isinstance(v, float) else f"{k}={v}"
+                    for k, v in PRESETS[name].items())

@@ -1,0 +1,171 @@
+/* flye_gpu.h -- C ABI of the MI355X-native overlap hot path (libflyegpu.so).
+ *
+ * Drop-in boundary for the two seams of Flye 2.8.1's sequence library
+ * (citations are into the reference tree):
+ *
+ *   index build        VertexIndex::countKmers / buildIndexUnevenCoverage /
+ *                      buildIndexMinimizers / clear / getSampleRate
+ *                      (src/sequence/vertex_index.h:213-218, :260;
+ *                       src/sequence/vertex_index.cpp:19-125, :389-483)
+ *   per-read overlaps  OverlapDetector::getSeqOverlaps, reached only through
+ *                      OverlapContainer::quickSeqOverlaps / lazySeqOverlaps
+ *                      (src/sequence/overlap.h:338-345, overlap.cpp:99-508,
+ *                       :518-574)
+ *
+ * The reference has no FFI: these entry points are what a C++ binding inside
+ * VertexIndex / OverlapContainer would call (see INTEGRATION.md for the stub).
+ * Conventions: every call returns an int status (FG_OK = 0, < 0 = error, text
+ * via fg_strerror); no exceptions cross the boundary; plain pointers + sizes;
+ * a context is bound to one HIP device and may be used by one host thread at
+ * a time.  There is NO CPU fallback: without a usable HIP device fg_create
+ * fails with FG_ERR_NO_DEVICE.
+ */
+#ifndef FLYE_GPU_H
+#define FLYE_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ABI_VERSION 1
+
+enum {
+	FG_OK = 0,
+	FG_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime failure at create */
+	FG_ERR_HIP = -2,         /* a HIP call failed; fg_last_error() has the text */
+	FG_ERR_ARG = -3,         /* bad argument */
+	FG_ERR_STATE = -4,       /* call order: reads not set / index not built */
+	FG_ERR_KMER_TOO_FREQUENT = -5, /* vertex_index.cpp:372 "k-mer is too frequent" */
+	FG_ERR_KMER_SIZE = -6,   /* k > 17 with the flat counter, vertex_index.cpp:504-507;
+	                            k > 32 never fits Kmer::KmerRepr (kmer.h:19) */
+	FG_ERR_UNSUPPORTED = -7, /* flag combination not built yet */
+	FG_ERR_NOMEM = -8
+};
+
+typedef struct fg_ctx fg_ctx;
+
+/* Parameters::get().kmerSize (src/common/config.h:103-115) is process-global
+ * in the reference; here it is a property of the context. */
+int  fg_create(fg_ctx** out, int device, int kmer_size);
+void fg_destroy(fg_ctx* ctx);
+const char* fg_strerror(int code);
+const char* fg_last_error(const fg_ctx* ctx);
+int  fg_abi_version(void);
+
+/* SequenceContainer contents (src/sequence/sequence_container.cpp:48-79,
+ * :359-392).  Forward strands only; the reverse complement of read i is
+ * implied (FastaRecord::Id first_seq_id + 2i is the forward record, +1 its
+ * reverse complement, sequence_container.h:27-33).  Packing is DnaSequence's
+ * (src/sequence/sequence.h:54-69): 32 nt per uint64, nt j at bits (j%32)*2,
+ * A,C,G,T = 0..3; each read starts on a word boundary; word_off has n+1
+ * entries.  N-replacement (sequence_container.cpp:318-328) stays with the
+ * caller because it draws from libc rand().  The buffers are copied to HBM;
+ * the caller may free them on return. */
+int fg_set_reads(fg_ctx* ctx, uint32_t n_fwd, const uint64_t* words,
+                 const uint64_t* word_off, const int32_t* len,
+                 uint32_t first_seq_id);
+
+struct fg_index_stats {
+	uint64_t total_kmers;      /* KmerCounter::_numKmers: distinct canonical k-mers
+	                              ("Total k-mers", vertex_index.cpp:589); 0 in
+	                              minimizer mode */
+	uint64_t selected_kmers;   /* _kmerIndex.size() ("Selected k-mers", :121, :473) */
+	uint64_t index_entries;    /* "Index size" (:122) / "K-mer index size" (:474) */
+	uint64_t repetitive_kmers; /* _repetitiveKmers.size() */
+	uint64_t repetitive_frequency; /* _repetitiveFrequency (:186) */
+	float    mean_frequency;   /* meanFrequency (:185) */
+	float    sample_rate;      /* VertexIndex::getSampleRate(): ctor value, or
+	                              totalLen/entries after buildIndexMinimizers (:480-482) */
+	double   build_seconds;    /* device time of the build, HIP events */
+};
+
+/* countKmers() + buildIndexUnevenCoverage(min_freq, select_rate, tandem_freq)
+ * with Config "repeat_kmer_rate" = repeat_rate (vertex_index.cpp:19-125,
+ * :173-212, :316-358, :499-590).  sample_rate_init is the VertexIndex ctor
+ * argument (main_assemble.cpp:195-196). */
+int fg_build_index_solid(fg_ctx* ctx, int32_t min_freq, float select_rate,
+                         int32_t tandem_freq, float repeat_rate,
+                         float sample_rate_init, struct fg_index_stats* out);
+
+/* buildIndexMinimizers(min_coverage, window) (vertex_index.cpp:389-483,
+ * kmer.h:206-262). */
+int fg_build_index_minimizers(fg_ctx* ctx, int32_t min_coverage, int32_t window,
+                              float repeat_rate, struct fg_index_stats* out);
+
+/* VertexIndex::clear() (vertex_index.cpp:486-496) */
+int fg_clear_index(fg_ctx* ctx);
+
+/* Read-only export of the built index for parity tests: keys ascending,
+ * key_off[n_keys+1] into entries; an entry is (record_index << 32) | position
+ * with record_index = FastaRecord id - first_seq_id, i.e. the same order as the
+ * reference's global position (vertex_index.cpp:108-114).  Pass NULL pointers
+ * to query the sizes. */
+int fg_export_index(fg_ctx* ctx, uint64_t* n_keys, uint64_t* n_entries,
+                    uint64_t* n_repetitive, uint64_t* keys, uint64_t* key_off,
+                    uint64_t* entries, uint64_t* repetitive_keys);
+
+/* OverlapDetector constructor arguments (overlap.h:313-336) */
+struct fg_detector_params {
+	int32_t max_jump;
+	int32_t min_overlap;
+	int32_t max_overhang;          /* 0 => _checkOverhang = false */
+	uint8_t keep_alignment;        /* kmerMatches output: FG_ERR_UNSUPPORTED if set */
+	uint8_t only_max_ext;          /* must be 1 for now */
+	uint8_t nucl_alignment;        /* edlib divergence (alignment.cpp:218-247) */
+	uint8_t partition_bad_mappings;/* FG_ERR_UNSUPPORTED if set */
+	uint8_t use_hpc;
+	uint8_t pad_[3];
+	float   max_divergence;        /* OverlapDetector::_maxDivergence (mutable,
+	                                  set by setDivergenceThreshold, overlap.cpp:820-827) */
+};
+
+/* One OverlapRange (overlap.h:20-279) plus the integers the float was made of.
+ * seq_divergence is computed on the HOST with glibc logf/float division from the
+ * device integers, exactly as overlap.cpp:417-423 / alignment.cpp:244-245 do. */
+struct fg_overlap_rec {
+	uint32_t cur_id, ext_id;
+	int32_t  cur_begin, cur_end, cur_len;
+	int32_t  ext_begin, ext_end, ext_len;
+	int32_t  score;
+	float    seq_divergence;
+	int32_t  chain_length;        /* chainLength (overlap.cpp:366) */
+	int32_t  filtered_positions;  /* repetitive query positions in range (:407-413) */
+	int32_t  edit_distance;       /* -1 unless nucl_alignment */
+	int32_t  hpc_len_cur, hpc_len_ext; /* compared string lengths (after HPC if on) */
+};
+
+struct fg_overlap_batch {
+	uint32_t n_queries;
+	uint64_t n_recs;
+	uint64_t* query_off;           /* n_queries + 1, into recs */
+	struct fg_overlap_rec* recs;   /* per query: reference emission order
+	                                  (ascending ext_id, overlap.cpp:216-234) */
+	uint64_t n_div_stats;
+	uint64_t* div_stats_off;       /* n_queries + 1 */
+	float*   div_stats;            /* OvlpDivStats::add() values (:488-506) */
+	/* work counters of this call (for the roofline's m and d) */
+	uint64_t query_bp, query_kmers, seed_hits, dp_groups, dp_elements;
+	double   device_seconds;       /* HIP-event time of the whole call */
+	void*    owner_;               /* library arena; release with fg_release_batch */
+};
+
+/* getSeqOverlaps for a batch of FastaRecord ids (forward or reverse-complement
+ * ids), as OverlapContainer::quickSeqOverlaps(id, max_overlaps, force_local)
+ * would return them one by one (overlap.cpp:518-526). */
+int fg_overlaps(fg_ctx* ctx, const struct fg_detector_params* p,
+                const uint32_t* query_ids, uint32_t n_queries,
+                int32_t max_overlaps, uint8_t force_local,
+                struct fg_overlap_batch* out);
+void fg_release_batch(struct fg_overlap_batch* b);
+
+/* Per-kernel device time of the most recent fg_overlaps / build call, measured
+ * with hipEvents on the library's own stream.  names[i] are static strings. */
+struct fg_kernel_time { const char* name; double seconds; uint64_t launches; };
+int fg_kernel_times(fg_ctx* ctx, struct fg_kernel_time* out, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

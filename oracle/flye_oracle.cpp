@@ -1,0 +1,859 @@
+// TEST INFRASTRUCTURE -- CPU restatement ("oracle") of Flye 2.8.1's overlap hot
+// path.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library, and only as the checker.  The product (libflyegpu.so) never
+// links, loads or calls anything in here.
+//
+// Parity status: PINNED -- checked record-for-record against the unmodified
+// reference compiled from /root/reference (oracle/_ref/ref_dumper; see
+// tests/test_oracle_vs_ref.py) and against the committed golden vectors that
+// the same dumper produced (tests/golden/, tests/test_oracle_golden.py).  The
+// reference's own tests hold no vectors for this path.
+//
+// This is a restatement of BEHAVIOUR on flat arrays, written from scratch; each
+// function cites the reference lines it follows.  The unstable sorts call the
+// real std::sort of this toolchain's libstdc++ (the same one the reference is
+// built with), which is what makes it the ground truth for the emulated
+// introsort of the HIP path (include/introsort_emul.h).
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <array>
+#include <deque>
+#include <functional>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/flye_gpu.h"
+#include "../include/introsort_emul.h"
+
+namespace {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+struct Hit { int32_t cur, ext; u32 extId; };
+
+// open-addressing map canonical k-mer -> (offset,count | repetitive)
+struct Slot { u64 key; u64 off; u32 cnt; u32 flag; };	// flag: 0 empty, 1 list, 2 repetitive
+
+struct Index {
+	std::vector<u64> keys;		// ascending canonical k-mers kept in _kmerIndex (may have empty lists)
+	std::vector<u64> keyOff;	// keys.size()+1
+	std::vector<u64> entries;	// global positions, ascending per key
+	std::vector<u64> repetitive;// ascending
+	std::vector<Slot> table;
+	u64 mask = 0;
+	float sampleRate = 1.0f;
+	bool built = false;
+};
+
+struct Ctx {
+	int k = 17;
+	u32 n = 0;
+	u32 firstId = 0;
+	std::vector<u64> words, wordOff;
+	std::vector<int32_t> len;
+	std::vector<u64> recOff;	// 2n+1 global offsets of records (fwd, rc interleaved)
+	Index idx;
+	// last overlap call
+	std::vector<u64> outOff, statOff;
+	std::vector<fg_overlap_rec> outRecs;
+	std::vector<float> outStats;
+	u64 cntKmers = 0, cntHits = 0, cntGroups = 0, cntDp = 0, cntBp = 0;
+};
+
+inline u64 mixHash(u64 x)
+{
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+	x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+	return x;
+}
+
+// sequence.h:120-129 atRaw(), with the lazy reverse-complement flag
+inline u32 baseAt(const Ctx& c, u32 read, int32_t pos, bool rc)
+{
+	int32_t L = c.len[read];
+	int32_t p = rc ? L - 1 - pos : pos;
+	u32 b = (u32)((c.words[c.wordOff[read] + (p >> 5)] >> ((p & 31) * 2)) & 3);
+	return rc ? (~b & 3) : b;
+}
+
+// kmer.h:16-109, :131-204: all k-mers of a strand at positions 0..len-k-1 (the
+// last one, at len-k, is never yielded), forward repr (first base most
+// significant), canonical = min(fwd, revcomp), flipped = revcomp < fwd.
+template <class F>
+inline void forEachKmer(const Ctx& c, u32 read, bool rc, F f)
+{
+	const int k = c.k;
+	const int32_t L = c.len[read];
+	if (L < k) return;
+	const int32_t nk = L - k;
+	const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+	u64 fw = 0, rv = 0;
+	for (int i = 0; i < k - 1; ++i)
+	{
+		u64 b = baseAt(c, read, i, rc);
+		fw = (fw << 2) | b;
+		rv = (rv >> 2) | ((3 - b) << (2 * (k - 1)));
+	}
+	for (int32_t p = 0; p < nk; ++p)
+	{
+		u64 b = baseAt(c, read, p + k - 1, rc);
+		fw = ((fw << 2) | b) & mask;
+		rv = (rv >> 2) | ((3 - b) << (2 * (k - 1)));
+		f(p, fw, rv);
+	}
+}
+
+// kmer.h:91-98 splitmix64 finaliser
+inline u64 kmerHash(u64 x)
+{
+	u64 z = (x += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+struct KmerPos { u64 fw; int32_t pos; };
+
+// kmer.h:206-262 yieldMinimizers: literal monotone-deque semantics
+void minimizers(const Ctx& c, u32 read, int window, std::vector<KmerPos>& out)
+{
+	out.clear();
+	if (window == 1)
+	{
+		forEachKmer(c, read, false, [&](int32_t p, u64 fw, u64) { out.push_back({fw, p}); });
+		return;
+	}
+	struct QE { u64 fw; int32_t pos; u64 hash; };
+	std::deque<QE> q;
+	forEachKmer(c, read, false, [&](int32_t p, u64 fw, u64 rv)
+	{
+		u64 h = kmerHash(std::min(fw, rv));
+		while (!q.empty() && q.back().hash > h) q.pop_back();
+		q.push_back({fw, p, h});
+		if (q.front().pos <= p - window)
+		{
+			while (q.front().pos <= p - window) q.pop_front();
+			while (q.size() >= 2 && q[0].hash == q[1].hash) q.pop_front();
+		}
+		if (out.empty() || out.back().pos != q.front().pos) out.push_back({q.front().fw, q.front().pos});
+	});
+}
+
+void parallelFor(u32 n, int threads, const std::function<void(u32, int)>& fn)
+{
+	if (threads <= 1 || n < 2)
+	{
+		for (u32 i = 0; i < n; ++i) fn(i, 0);
+		return;
+	}
+	std::atomic<u32> next(0);
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; ++t)
+		pool.emplace_back([&, t]()
+		{
+			while (true)
+			{
+				u32 i = next.fetch_add(1);
+				if (i >= n) return;
+				fn(i, t);
+			}
+		});
+	for (auto& th : pool) th.join();
+}
+
+// sequence_container.cpp:359-392 + .h:200-213: global position of (record, pos)
+inline u64 globalPos(const Ctx& c, u32 rec, int32_t pos) { return c.recOff[rec] + (u64)pos; }
+
+// sequence_container.h:220-235 seqPosition (binary search instead of hint table)
+inline void seqPosition(const Ctx& c, u64 g, u32& rec, int32_t& pos, int32_t& len)
+{
+	size_t hi = std::upper_bound(c.recOff.begin(), c.recOff.end(), g) - c.recOff.begin();
+	rec = (u32)(hi - 1);
+	pos = (int32_t)(g - c.recOff[rec]);
+	len = c.len[rec >> 1];
+}
+
+void buildTable(Index& ix)
+{
+	size_t need = (ix.keys.size() + ix.repetitive.size()) * 2 + 16;
+	size_t cap = 16;
+	while (cap < need) cap <<= 1;
+	ix.table.assign(cap, Slot{0, 0, 0, 0});
+	ix.mask = cap - 1;
+	auto put = [&](u64 key, u64 off, u32 cnt, u32 flag)
+	{
+		u64 h = mixHash(key) & ix.mask;
+		while (ix.table[h].flag) h = (h + 1) & ix.mask;
+		ix.table[h] = Slot{key, off, cnt, flag};
+	};
+	for (size_t i = 0; i < ix.keys.size(); ++i)
+		put(ix.keys[i], ix.keyOff[i], (u32)(ix.keyOff[i + 1] - ix.keyOff[i]), 1);
+	for (u64 r : ix.repetitive) put(r, 0, 0, 2);
+	ix.built = true;
+}
+
+inline const Slot* lookup(const Index& ix, u64 key)
+{
+	u64 h = mixHash(key) & ix.mask;
+	while (ix.table[h].flag)
+	{
+		if (ix.table[h].key == key) return &ix.table[h];
+		h = (h + 1) & ix.mask;
+	}
+	return nullptr;
+}
+
+// vertex_index.cpp:173-212 filterFrequentKmers on (key, capacity) pairs
+void filterFrequent(std::vector<u64>& keys, std::vector<u32>& cap, int minCoverage, float rate,
+					std::vector<u64>& repetitive, fg_index_stats& st)
+{
+	size_t total = 0, unique = 0;
+	for (size_t i = 0; i < keys.size(); ++i)
+		if (cap[i] >= (size_t)minCoverage) { total += cap[i]; unique += 1; }
+	float mean = (float)total / (unique + 1);
+	size_t repFreq = rate * mean;
+	std::vector<u64> k2; std::vector<u32> c2;
+	for (size_t i = 0; i < keys.size(); ++i)
+	{
+		if (cap[i] > repFreq) repetitive.push_back(keys[i]);
+		else { k2.push_back(keys[i]); c2.push_back(cap[i]); }
+	}
+	keys.swap(k2); cap.swap(c2);
+	st.mean_frequency = mean;
+	st.repetitive_frequency = repFreq;
+}
+
+// run-length encode a sorted vector
+void rle(const std::vector<u64>& v, std::vector<u64>& keys, std::vector<u32>& cnt)
+{
+	keys.clear(); cnt.clear();
+	for (size_t i = 0; i < v.size();)
+	{
+		size_t j = i;
+		while (j < v.size() && v[j] == v[i]) ++j;
+		keys.push_back(v[i]); cnt.push_back((u32)(j - i));
+		i = j;
+	}
+}
+
+struct Sel { u64 canon; u64 gpos; u32 freq; };
+
+// vertex_index.cpp:316-358 yieldFrequentKmers for one forward read; freq lookups
+// through a sorted (key,count) table = KmerCounter::getFreq (:593-616, exact count)
+void selectFrequent(const Ctx& c, u32 read, const std::vector<u64>& cKeys, const std::vector<u32>& cCnt,
+					float selectRate, int tandemFreq, std::vector<Sel>& out)
+{
+	out.clear();
+	struct P { u64 canon; int32_t pos; bool flip; u32 freq; };
+	std::vector<P> all;
+	forEachKmer(c, read, false, [&](int32_t p, u64 fw, u64 rv)
+	{
+		bool flip = rv < fw;
+		u64 cn = flip ? rv : fw;
+		size_t j = std::lower_bound(cKeys.begin(), cKeys.end(), cn) - cKeys.begin();
+		all.push_back({cn, p, flip, cCnt[j]});
+	});
+	if (all.empty()) return;
+	std::vector<u32> fr(all.size());
+	for (size_t i = 0; i < all.size(); ++i) fr[i] = all[i].freq;
+	std::sort(fr.begin(), fr.end(), [](u32 a, u32 b) { return a > b; });
+	const size_t maxKmers = selectRate * all.size();
+	const u32 minFreq = fr[maxKmers];
+	std::unordered_map<u64, u32> local;
+	for (auto& p : all) ++local[p.canon];
+	const int32_t L = c.len[read];
+	for (auto& p : all)
+	{
+		if (p.freq < minFreq) continue;
+		if (tandemFreq > 0 && local[p.canon] > (u32)tandemFreq) continue;
+		// canonical orientation: vertex_index.cpp:76-85
+		u32 rec = 2 * read + (p.flip ? 1 : 0);
+		int32_t pos = p.flip ? L - p.pos - c.k : p.pos;
+		out.push_back({p.canon, globalPos(c, rec, pos), p.freq});
+	}
+}
+
+void finishIndex(Ctx& c, std::vector<u64>& keys, std::vector<std::pair<u64, u64>>& ent, fg_index_stats& st)
+{
+	// ent = (canon, gpos) for every accepted position; keys = _kmerIndex keys (ascending)
+	std::sort(ent.begin(), ent.end());
+	Index& ix = c.idx;
+	ix.keys = keys;
+	ix.keyOff.assign(keys.size() + 1, 0);
+	ix.entries.resize(ent.size());
+	size_t e = 0;
+	for (size_t i = 0; i < keys.size(); ++i)
+	{
+		ix.keyOff[i] = e;
+		while (e < ent.size() && ent[e].first == keys[i]) { ix.entries[e] = ent[e].second; ++e; }
+	}
+	ix.keyOff[keys.size()] = e;
+	st.selected_kmers = keys.size();
+	st.index_entries = ent.size();
+	st.repetitive_kmers = ix.repetitive.size();
+	buildTable(ix);
+}
+
+} // namespace
+
+extern "C" {
+
+struct fo_ctx { Ctx c; };
+
+fo_ctx* fo_create(int k) { fo_ctx* h = new fo_ctx; h->c.k = k; return h; }
+void fo_destroy(fo_ctx* h) { delete h; }
+
+int fo_set_reads(fo_ctx* h, u32 n, const u64* words, const u64* wordOff, const int32_t* len, u32 firstId)
+{
+	Ctx& c = h->c;
+	c.n = n; c.firstId = firstId;
+	c.wordOff.assign(wordOff, wordOff + n + 1);
+	c.words.assign(words, words + wordOff[n]);
+	c.len.assign(len, len + n);
+	c.recOff.assign(2 * (size_t)n + 1, 0);
+	u64 off = 0;
+	for (u32 i = 0; i < n; ++i)
+	{
+		c.recOff[2 * i] = off; off += len[i];
+		c.recOff[2 * i + 1] = off; off += len[i];
+	}
+	c.recOff[2 * (size_t)n] = off;
+	c.idx = Index();
+	return 0;
+}
+
+// countKmers + buildIndexUnevenCoverage (vertex_index.cpp:19-125, :499-590)
+int fo_build_index_solid(fo_ctx* h, int32_t minFreq, float selectRate, int32_t tandemFreq,
+						 float repeatRate, float sampleRateInit, int threads, fg_index_stats* st)
+{
+	Ctx& c = h->c;
+	if (c.k > 17) return FG_ERR_KMER_SIZE;
+	memset(st, 0, sizeof(*st));
+	c.idx = Index();
+	c.idx.sampleRate = sampleRateInit;
+	// exact counts of canonical k-mers over forward reads
+	std::vector<u64> all;
+	for (u32 r = 0; r < c.n; ++r)
+		forEachKmer(c, r, false, [&](int32_t, u64 fw, u64 rv) { all.push_back(std::min(fw, rv)); });
+	std::sort(all.begin(), all.end());
+	std::vector<u64> cKeys; std::vector<u32> cCnt;
+	rle(all, cKeys, cCnt);
+	std::vector<u64>().swap(all);
+	st->total_kmers = cKeys.size();
+
+	// pass 1 (:41-59): capacities of selected k-mers with freq >= minFreq
+	std::vector<std::vector<Sel>> sel(c.n);
+	parallelFor(c.n, threads, [&](u32 r, int) { selectFrequent(c, r, cKeys, cCnt, selectRate, tandemFreq, sel[r]); });
+	std::vector<u64> capList;
+	for (auto& v : sel) for (auto& s : v) if (s.freq >= (u32)minFreq) capList.push_back(s.canon);
+	std::sort(capList.begin(), capList.end());
+	std::vector<u64> keys; std::vector<u32> cap;
+	rle(capList, keys, cap);
+	filterFrequent(keys, cap, minFreq, repeatRate, c.idx.repetitive, *st);
+	for (u32 cp : cap) if ((size_t)cp + 1 > 32 * 1024 * 1024 / 5) return FG_ERR_KMER_TOO_FREQUENT; // :370-373
+
+	// pass 2 (:65-104)
+	std::vector<std::pair<u64, u64>> ent;
+	for (auto& v : sel)
+		for (auto& s : v)
+		{
+			if (s.freq < (u32)minFreq || s.freq > st->repetitive_frequency) continue;
+			if (!std::binary_search(keys.begin(), keys.end(), s.canon)) continue;
+			ent.push_back({s.canon, s.gpos});
+		}
+	finishIndex(c, keys, ent, *st);
+	st->sample_rate = c.idx.sampleRate;
+	return 0;
+}
+
+// buildIndexMinimizers (vertex_index.cpp:389-483)
+int fo_build_index_minimizers(fo_ctx* h, int32_t minCoverage, int32_t window, float repeatRate,
+							  int threads, fg_index_stats* st)
+{
+	Ctx& c = h->c;
+	if (window < 1) return FG_ERR_ARG;
+	memset(st, 0, sizeof(*st));
+	c.idx = Index();
+	size_t totalLen = 0;
+	for (u32 r = 0; r < c.n; ++r) totalLen += c.len[r];
+	std::vector<std::vector<KmerPos>> mins(c.n);
+	parallelFor(c.n, threads, [&](u32 r, int) { minimizers(c, r, window, mins[r]); });
+	const int k = c.k;
+	std::vector<u64> capList;
+	auto canonOf = [k](u64 fw, bool& flip)
+	{
+		u64 rv = 0, t = fw;
+		for (int i = 0; i < k; ++i) { rv = (rv << 2) | (~t & 3); t >>= 2; }
+		flip = rv < fw;
+		return flip ? rv : fw;
+	};
+	for (auto& v : mins) for (auto& m : v) { bool f; capList.push_back(canonOf(m.fw, f)); }
+	std::sort(capList.begin(), capList.end());
+	std::vector<u64> keys; std::vector<u32> cap;
+	rle(capList, keys, cap);
+	filterFrequent(keys, cap, minCoverage, repeatRate, c.idx.repetitive, *st);
+	for (u32 cp : cap) if ((size_t)cp + 1 > 32 * 1024 * 1024 / 5) return FG_ERR_KMER_TOO_FREQUENT;
+	std::vector<std::pair<u64, u64>> ent;
+	for (u32 r = 0; r < c.n; ++r)
+		for (auto& m : mins[r])
+		{
+			bool flip; u64 cn = canonOf(m.fw, flip);
+			if (!std::binary_search(keys.begin(), keys.end(), cn)) continue;	// repetitive (:442)
+			u32 rec = 2 * r + (flip ? 1 : 0);
+			int32_t pos = flip ? c.len[r] - m.pos - k : m.pos;
+			ent.push_back({cn, globalPos(c, rec, pos)});
+		}
+	finishIndex(c, keys, ent, *st);
+	float rate = (float)totalLen / ent.size();	// :480-482
+	c.idx.sampleRate = rate;
+	st->sample_rate = rate;
+	return 0;
+}
+
+// minimizer sketch of one forward read, for kernel-level parity tests
+int64_t fo_minimizers(fo_ctx* h, u32 read, int window, int32_t* posOut, int64_t cap)
+{
+	std::vector<KmerPos> v;
+	minimizers(h->c, read, window, v);
+	for (size_t i = 0; i < v.size() && (int64_t)i < cap; ++i) posOut[i] = v[i].pos;
+	return (int64_t)v.size();
+}
+
+// import an index built elsewhere (entries as (record<<32|pos)); used by bench's
+// cpu_baseline leg so the CPU times the overlap stage on the same index
+int fo_import_index(fo_ctx* h, u64 nKeys, const u64* keys, const u64* keyOff, const u64* entries,
+					u64 nRep, const u64* rep, float sampleRate)
+{
+	Ctx& c = h->c;
+	Index& ix = c.idx;
+	ix = Index();
+	ix.keys.assign(keys, keys + nKeys);
+	ix.keyOff.assign(keyOff, keyOff + nKeys + 1);
+	ix.entries.resize(keyOff[nKeys]);
+	for (u64 i = 0; i < keyOff[nKeys]; ++i)
+		ix.entries[i] = c.recOff[entries[i] >> 32] + (entries[i] & 0xffffffffu);
+	ix.repetitive.assign(rep, rep + nRep);
+	ix.sampleRate = sampleRate;
+	buildTable(ix);
+	return 0;
+}
+
+// same export form as fg_export_index
+int fo_export_index(fo_ctx* h, u64* nKeys, u64* nEntries, u64* nRep, u64* keys, u64* keyOff,
+					u64* entries, u64* rep)
+{
+	Ctx& c = h->c;
+	const Index& ix = c.idx;
+	if (!ix.built) return FG_ERR_STATE;
+	*nKeys = ix.keys.size(); *nEntries = ix.entries.size(); *nRep = ix.repetitive.size();
+	if (keys) memcpy(keys, ix.keys.data(), ix.keys.size() * 8);
+	if (keyOff) memcpy(keyOff, ix.keyOff.data(), ix.keyOff.size() * 8);
+	if (entries)
+		for (size_t i = 0; i < ix.entries.size(); ++i)
+		{
+			u32 rec; int32_t pos, len;
+			seqPosition(c, ix.entries[i], rec, pos, len);
+			entries[i] = ((u64)rec << 32) | (u32)pos;
+		}
+	if (rep) memcpy(rep, ix.repetitive.data(), ix.repetitive.size() * 8);
+	return 0;
+}
+
+} // extern "C"
+
+namespace {
+
+// alignment.cpp:52-70 homopolymerCompression of seq[start, start+length)
+void extractSeq(const Ctx& c, u32 recIdx, int32_t start, int32_t length, bool hpc, std::vector<uint8_t>& out)
+{
+	out.clear();
+	const u32 read = recIdx >> 1;
+	const bool rc = recIdx & 1;
+	for (int32_t i = 0; i < length; ++i)
+	{
+		uint8_t b = (uint8_t)baseAt(c, read, start + i, rc);
+		if (!hpc || i == 0 || out.back() != b) out.push_back(b);
+	}
+}
+
+// exact unit-cost global edit distance (what edlibAlign(NW, DISTANCE, k=-1)
+// returns, edlib.cpp:141-296): Ukkonen band doubling over a plain DP.
+int editDistance(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
+{
+	const int n = (int)a.size(), m = (int)b.size();
+	if (n == 0) return m;
+	if (m == 0) return n;
+	const int INF = 1 << 29;
+	int kband = std::max(64, std::abs(n - m) + 1);
+	std::vector<int> prev, cur;
+	while (true)
+	{
+		// cells (i,j) with |i-j| <= kband
+		prev.assign(m + 2, INF); cur.assign(m + 2, INF);
+		for (int j = 0; j <= std::min(m, kband); ++j) prev[j] = j;
+		for (int i = 1; i <= n; ++i)
+		{
+			int lo = std::max(0, i - kband), hi = std::min(m, i + kband);
+			if (lo > 0) cur[lo - 1] = INF;
+			for (int j = lo; j <= hi; ++j)
+			{
+				int v;
+				if (j == 0) v = i;
+				else
+				{
+					v = prev[j - 1] + (a[i - 1] != b[j - 1]);
+					if (prev[j] + 1 < v) v = prev[j] + 1;
+					if (j > lo && cur[j - 1] + 1 < v) v = cur[j - 1] + 1;
+				}
+				cur[j] = v;
+			}
+			if (hi < m) cur[hi + 1] = INF;
+			prev.swap(cur);
+		}
+		int d = prev[m];
+		if (d <= kband) return d;
+		kband *= 2;
+	}
+}
+
+struct Cand {
+	int32_t curBegin, curEnd, extBegin, extEnd, score, chainLength, filtered;
+	float div;
+};
+
+// overlap.cpp:29-69 overlapTest
+bool overlapTest(const fg_detector_params& P, u32 curId, u32 extId, int32_t curLen, int32_t extLen,
+				 const Cand& o, bool forceLocal)
+{
+	int32_t curRange = o.curEnd - o.curBegin, extRange = o.extEnd - o.extBegin;
+	if (curRange < P.min_overlap || extRange < P.min_overlap) return false;
+	const float OVLP_DIV = 0.5;
+	float lengthDiff = abs(curRange - extRange);
+	if (lengthDiff > OVLP_DIV * std::min(curRange, extRange)) return false;
+	if (curId == extId)
+	{
+		int32_t inter = std::min(o.curEnd, o.extEnd) - std::max(o.curBegin, o.extBegin);
+		if (inter > curRange / 2) return false;
+	}
+	if (curId == (extId ^ 1))
+	{
+		int32_t inter = std::min(o.curEnd, extLen - o.extBegin) - std::max(o.curBegin, extLen - o.extEnd);
+		if (inter > curRange / 2) return false;
+	}
+	if (!forceLocal && P.max_overhang > 0)
+	{
+		int32_t ovh = std::max(std::min(o.curBegin, o.extBegin),
+							   std::min(curLen - o.curEnd, extLen - o.extEnd));
+		if (ovh > P.max_overhang) return false;
+	}
+	return true;
+}
+
+struct Scratch {
+	std::vector<Hit> hits, group;
+	std::vector<int32_t> score, back, filtered;
+	std::vector<size_t> order;
+	std::vector<uint8_t> sa, sb;
+};
+
+// overlap.cpp:99-508 getSeqOverlaps for one FastaRecord (recIdx = id - firstId)
+void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool forceLocal, int maxOverlaps,
+				 Scratch& S, std::vector<fg_overlap_rec>& out, std::vector<float>& stats, u64* counters)
+{
+	const Index& ix = c.idx;
+	const int k = c.k;
+	const u32 read = recIdx >> 1;
+	const bool qrc = recIdx & 1;
+	const int32_t curLen = c.len[read];
+	const u32 curId = c.firstId + recIdx;
+	const float minKmerSurvivalRate = 0.01;
+	const float LG_GAP = 2, SM_GAP = 0.5;
+	S.hits.clear(); S.filtered.clear();
+
+	// seed collection (:176-196); lookups as vertex_index.h:139-246
+	forEachKmer(c, read, qrc, [&](int32_t p, u64 fw, u64 rv)
+	{
+		++counters[0];
+		bool flip = rv < fw;
+		const Slot* s = lookup(ix, flip ? rv : fw);
+		if (!s) return;
+		if (s->flag == 2) { S.filtered.push_back(p); return; }
+		for (u32 j = 0; j < s->cnt; ++j)
+		{
+			u32 rec; int32_t pos, len;
+			seqPosition(c, ix.entries[s->off + j], rec, pos, len);
+			if (flip) { rec ^= 1; pos = len - pos - k; }
+			if (rec == recIdx && pos == p) continue;	// no trivial matches
+			S.hits.push_back({p, pos, c.firstId + rec});
+		}
+	});
+	counters[1] += S.hits.size();
+
+	std::sort(S.hits.begin(), S.hits.end(), [](const Hit& a, const Hit& b)
+			  { return a.extId != b.extId ? a.extId < b.extId : a.cur < b.cur; });
+
+	const int STAT_WND = 10000;
+	struct Wnd { int32_t range; float div; };
+	std::vector<Wnd> wnd(curLen / STAT_WND + 1, Wnd{0, 0.0f});
+	size_t detected = 0;
+
+	size_t gEnd = 0;
+	const size_t nh = S.hits.size();
+	while (gEnd < nh)
+	{
+		if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
+		size_t gBeg = gEnd;
+		size_t unique = 0;
+		int32_t prev = 0;
+		while (gEnd < nh && S.hits[gBeg].extId == S.hits[gEnd].extId)
+		{
+			if (S.hits[gEnd].cur != prev) { ++unique; prev = S.hits[gEnd].cur; }
+			++gEnd;
+		}
+		if (unique < minKmerSurvivalRate * P.min_overlap) continue;
+
+		S.group.assign(S.hits.begin() + gBeg, S.hits.begin() + gEnd);
+		std::vector<Hit>& M = S.group;
+		const u32 extId = M.front().extId;
+		const u32 extRec = extId - c.firstId;
+		const int32_t extLen = c.len[extRec >> 1];
+
+		int32_t minCur = M.front().cur, maxCur = M.back().cur;
+		int32_t minExt = INT32_MAX, maxExt = INT32_MIN;
+		for (auto& m : M) { minExt = std::min(minExt, m.ext); maxExt = std::max(maxExt, m.ext); }
+		if (maxCur - minCur < P.min_overlap || maxExt - minExt < P.min_overlap) continue;
+		if (P.max_overhang > 0 && !forceLocal)
+		{
+			if (std::min(minCur, minExt) > P.max_overhang) continue;
+			if (std::min(curLen - maxCur, extLen - maxExt) > P.max_overhang) continue;
+		}
+		++counters[2];
+		counters[3] += M.size();
+
+		const int32_t n = (int32_t)M.size();
+		S.score.assign(n, 0);
+		S.back.assign(n, -1);
+		const bool extSorted = extLen > curLen;
+		if (extSorted)
+			std::sort(M.begin(), M.end(), [](const Hit& a, const Hit& b) { return a.ext < b.ext; });
+
+		// chaining DP (:277-323)
+		for (int32_t i = 1; i < n; ++i)
+		{
+			int32_t maxScore = 0, maxId = 0;
+			const int32_t curNext = M[i].cur, extNext = M[i].ext;
+			for (int32_t j = i - 1; j >= 0; --j)
+			{
+				const int32_t curPrev = M[j].cur, extPrev = M[j].ext;
+				if (0 < curNext - curPrev && curNext - curPrev < P.max_jump &&
+					0 < extNext - extPrev && extNext - extPrev < P.max_jump)
+				{
+					int32_t matchScore = std::min(std::min(curNext - curPrev, extNext - extPrev), k);
+					int32_t jumpDiv = abs((curNext - curPrev) - (extNext - extPrev));
+					int32_t gapCost = (jumpDiv > 100 ? LG_GAP : SM_GAP) * jumpDiv;
+					int32_t nextScore = S.score[j] + matchScore - gapCost;
+					if (nextScore > maxScore)
+					{
+						maxScore = nextScore;
+						maxId = j;
+						if (jumpDiv == 0 && curNext - curPrev < k) break;
+					}
+				}
+				if (extSorted && extNext - extPrev > P.max_jump) break;
+				if (!extSorted && curNext - curPrev > P.max_jump) break;
+			}
+			S.score[i] = std::max(maxScore, k);
+			if (maxScore > k) S.back[i] = maxId;
+		}
+
+		// backtracking in descending score order (:326-427)
+		S.order.resize(n);
+		std::iota(S.order.begin(), S.order.end(), 0);
+		const std::vector<int32_t>& sc = S.score;
+		std::sort(S.order.begin(), S.order.end(), [&sc](size_t a, size_t b) { return sc[a] > sc[b]; });
+
+		std::vector<Cand> cands;
+		for (size_t oi = 0; oi < S.order.size(); ++oi)
+		{
+			int32_t start = (int32_t)S.order[oi];
+			if (S.back[start] == -1) continue;
+			int32_t last = start, first = 0, chainLength = 0;
+			int32_t pos = start;
+			while (pos != -1)
+			{
+				first = pos;
+				++chainLength;
+				int32_t np = S.back[pos];
+				S.back[pos] = -1;
+				pos = np;
+			}
+			Cand o;
+			o.curBegin = M[first].cur; o.extBegin = M[first].ext;
+			o.curEnd = M[last].cur + k - 1; o.extEnd = M[last].ext + k - 1;
+			o.score = S.score[last] - S.score[first] + k - 1;
+			o.chainLength = chainLength;
+			if (!overlapTest(P, curId, extId, curLen, extLen, o, forceLocal)) continue;
+			int32_t fpos = 0;
+			for (int32_t p : S.filtered)
+			{
+				if (p < o.curBegin) continue;
+				if (p > o.curEnd) break;
+				++fpos;
+			}
+			o.filtered = fpos;
+			float normLen = std::max(o.curEnd - o.curBegin, o.extEnd - o.extBegin) - fpos;
+			float matchRate = (float)chainLength * ix.sampleRate / normLen;
+			matchRate = std::min(matchRate, 1.0f);
+			o.div = std::log(1 / matchRate) / k;
+			cands.push_back(o);
+		}
+
+		// primary selection (:431-458)
+		std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.score > b.score; });
+		std::vector<Cand> prim;
+		if (P.only_max_ext) { if (!cands.empty()) prim.push_back(cands.front()); }
+		else
+		{
+			for (auto& o : cands)
+			{
+				bool contained = false;
+				for (auto& p : prim)
+					if (p.curBegin <= o.curBegin && o.curEnd <= p.curEnd &&
+						p.extBegin <= o.extBegin && o.extEnd <= p.extEnd && p.score > o.score)
+					{ contained = true; break; }
+				if (!contained) prim.push_back(o);
+			}
+		}
+
+		// divergence gate (:461-493)
+		for (auto& o : prim)
+		{
+			fg_overlap_rec r;
+			r.cur_id = curId; r.ext_id = extId;
+			r.cur_begin = o.curBegin; r.cur_end = o.curEnd; r.cur_len = curLen;
+			r.ext_begin = o.extBegin; r.ext_end = o.extEnd; r.ext_len = extLen;
+			r.score = o.score; r.chain_length = o.chainLength; r.filtered_positions = o.filtered;
+			r.edit_distance = -1; r.hpc_len_cur = 0; r.hpc_len_ext = 0;
+			float div = o.div;
+			if (P.nucl_alignment)
+			{
+				// alignment.cpp:218-247 getAlignmentErrEdlib
+				extractSeq(c, recIdx, o.curBegin, o.curEnd - o.curBegin, P.use_hpc, S.sa);
+				extractSeq(c, extRec, o.extBegin, o.extEnd - o.extBegin, P.use_hpc, S.sb);
+				int d = editDistance(S.sb, S.sa);
+				r.edit_distance = d;
+				r.hpc_len_cur = (int32_t)S.sa.size(); r.hpc_len_ext = (int32_t)S.sb.size();
+				div = (float)d / std::max(S.sb.size(), S.sa.size());
+			}
+			r.seq_divergence = div;
+			if (div < P.max_divergence) { out.push_back(r); ++detected; }
+			size_t w = o.curBegin / STAT_WND;
+			if (o.curEnd - o.curBegin > wnd[w].range) { wnd[w].range = o.curEnd - o.curBegin; wnd[w].div = div; }
+		}
+	}
+	for (auto& w : wnd) if (w.range > 0) stats.push_back(w.div);
+}
+
+} // namespace
+
+extern "C" {
+
+int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32 nq, int32_t maxOverlaps,
+				uint8_t forceLocal, int threads, u64* nRecs, u64* nStats)
+{
+	Ctx& c = h->c;
+	if (!c.idx.built) return FG_ERR_STATE;
+	if (P->keep_alignment || P->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	std::vector<std::vector<fg_overlap_rec>> res(nq);
+	std::vector<std::vector<float>> st(nq);
+	int T = std::max(1, threads);
+	std::vector<Scratch> scratch(T);
+	std::vector<std::array<u64, 4>> cnt(T, std::array<u64, 4>{0, 0, 0, 0});
+	for (u32 i = 0; i < nq; ++i)
+		if (queryIds[i] < c.firstId || queryIds[i] - c.firstId >= 2 * c.n) return FG_ERR_ARG;
+	parallelFor(nq, T, [&](u32 i, int t)
+	{
+		seqOverlaps(c, *P, queryIds[i] - c.firstId, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data());
+	});
+	c.outOff.assign(nq + 1, 0); c.statOff.assign(nq + 1, 0);
+	c.outRecs.clear(); c.outStats.clear();
+	c.cntBp = 0;
+	for (u32 i = 0; i < nq; ++i)
+	{
+		c.outOff[i] = c.outRecs.size(); c.statOff[i] = c.outStats.size();
+		c.outRecs.insert(c.outRecs.end(), res[i].begin(), res[i].end());
+		c.outStats.insert(c.outStats.end(), st[i].begin(), st[i].end());
+		c.cntBp += c.len[(queryIds[i] - c.firstId) >> 1];
+	}
+	c.outOff[nq] = c.outRecs.size(); c.statOff[nq] = c.outStats.size();
+	c.cntKmers = c.cntHits = c.cntGroups = c.cntDp = 0;
+	for (auto& a : cnt) { c.cntKmers += a[0]; c.cntHits += a[1]; c.cntGroups += a[2]; c.cntDp += a[3]; }
+	*nRecs = c.outRecs.size(); *nStats = c.outStats.size();
+	return 0;
+}
+
+int fo_fetch(fo_ctx* h, u64* queryOff, fg_overlap_rec* recs, u64* statOff, float* stats, u64* counters)
+{
+	Ctx& c = h->c;
+	if (queryOff) memcpy(queryOff, c.outOff.data(), c.outOff.size() * 8);
+	if (recs) memcpy(recs, c.outRecs.data(), c.outRecs.size() * sizeof(fg_overlap_rec));
+	if (statOff) memcpy(statOff, c.statOff.data(), c.statOff.size() * 8);
+	if (stats) memcpy(stats, c.outStats.data(), c.outStats.size() * 4);
+	if (counters)
+	{
+		counters[0] = c.cntBp; counters[1] = c.cntKmers; counters[2] = c.cntHits;
+		counters[3] = c.cntGroups; counters[4] = c.cntDp;
+	}
+	return 0;
+}
+
+// exact NW edit distance of two 0..3 strings (kernel-level parity tests)
+int fo_edit_distance(const uint8_t* a, int n, const uint8_t* b, int m)
+{
+	std::vector<uint8_t> va(a, a + n), vb(b, b + m);
+	return editDistance(va, vb);
+}
+
+// ---- introsort emulation self-test against the real std::sort ---------------
+struct KV { u64 key; u32 val; };
+struct KVAcc {
+	typedef KV T;
+	KV* p;
+	KV load(int i) const { return p[i]; }
+	void store(int i, const KV& v) { p[i] = v; }
+	bool less(const KV& a, const KV& b) const { return a.key < b.key; }
+};
+
+// sorts (keys, vals) with the emulation and with std::sort; returns the number of
+// positions where the two permutations differ (0 = identical)
+int64_t fo_introsort_mismatches(const u64* keys, int64_t n)
+{
+	std::vector<KV> a(n), b(n);
+	for (int64_t i = 0; i < n; ++i) { a[i] = {keys[i], (u32)i}; b[i] = a[i]; }
+	std::sort(a.begin(), a.end(), [](const KV& x, const KV& y) { return x.key < y.key; });
+	KVAcc acc{b.data()};
+	int stack[fgsort::STACK_INTS];
+	fgsort::sort(acc, 0, (int)n, stack);
+	int64_t bad = 0;
+	for (int64_t i = 0; i < n; ++i) bad += (a[i].val != b[i].val) || (a[i].key != b[i].key);
+	return bad;
+}
+
+// std::sort permutation itself (vals out) so GPU kernels can be checked directly
+void fo_std_sort_perm(const u64* keys, int64_t n, u32* permOut)
+{
+	std::vector<KV> a(n);
+	for (int64_t i = 0; i < n; ++i) a[i] = {keys[i], (u32)i};
+	std::sort(a.begin(), a.end(), [](const KV& x, const KV& y) { return x.key < y.key; });
+	for (int64_t i = 0; i < n; ++i) permOut[i] = a[i].val;
+}
+
+} // extern "C"

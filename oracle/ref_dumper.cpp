@@ -1,0 +1,208 @@
+// TEST INFRASTRUCTURE -- not shipped, never on the product path.
+//
+// Driver around the UNMODIFIED reference (Flye 2.8.1) sources where they lie
+// under /root/reference: loads a FASTA/FASTQ through the reference's own
+// SequenceContainer, builds the reference VertexIndex exactly the way
+// src/assemble/main_assemble.cpp:158-242 does, runs
+// OverlapContainer::quickSeqOverlaps() for every forward read through the
+// reference's processInParallel, and prints index contents and OverlapRange
+// records in a stable text form (floats as raw bit patterns).
+//
+// Built only by oracle/Makefile into oracle/_ref/ (git-ignored).  It is the
+// generator of tests/golden/* and the "reference" CPU baseline of bench.py.
+// No reference source text is copied here; the reference is reached through
+// its headers and object files.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include <cuckoohash_map.hh>
+#include "IntervalTree.h"
+
+// the dumper needs to read private index state; class layout is unaffected
+#define private public
+#define protected public
+#include "sequence/sequence_container.h"
+#include "sequence/vertex_index.h"
+#include "sequence/overlap.h"
+#include "common/config.h"
+#include "common/parallel.h"
+#undef private
+#undef protected
+
+static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+int main(int argc, char** argv)
+{
+	std::string reads, params, config, indexOut, ovlpOut, divMode = "none";
+	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
+	int minOverlap = 1000;	// main_assemble.cpp:174
+	long queryLimit = -1;
+	bool rcQueries = false;
+	for (int i = 1; i < argc; ++i)
+	{
+		std::string a = argv[i];
+		auto next = [&]() { return std::string(argv[++i]); };
+		if (a == "--reads") reads = next();
+		else if (a == "--params") params = next();
+		else if (a == "--config") config = next();
+		else if (a == "--threads") threads = atoi(next().c_str());
+		else if (a == "--min-read-len") minReadLen = atoi(next().c_str());
+		else if (a == "--max-overlaps") maxOverlaps = atoi(next().c_str());
+		else if (a == "--force-local") forceLocal = atoi(next().c_str());
+		else if (a == "--min-overlap") minOverlap = atoi(next().c_str());
+		else if (a == "--div-mode") divMode = next();
+		else if (a == "--index-out") indexOut = next();
+		else if (a == "--ovlp-out") ovlpOut = next();
+		else if (a == "--query-limit") queryLimit = atol(next().c_str());
+		else if (a == "--rc-queries") rcQueries = true;
+		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
+	}
+	if (!config.empty()) Config::load(config);
+	if (!params.empty()) Config::addParameters(params);
+	Parameters::get().numThreads = threads;
+	Parameters::get().kmerSize = (int)Config::get("kmer_size");
+	Parameters::get().minimumOverlap = minOverlap;
+	Parameters::get().unevenCoverage = false;
+
+	using clk = std::chrono::steady_clock;
+	auto t0 = clk::now();
+	SequenceContainer readsContainer;
+	readsContainer.loadFromFile(reads, minReadLen);
+	readsContainer.buildPositionIndex();
+	auto t1 = clk::now();
+
+	VertexIndex vertexIndex(readsContainer, (int)Config::get("assemble_kmer_sample"));
+	const int MIN_FREQ = 2;
+	bool useMinimizers = Config::get("use_minimizers");
+	if (useMinimizers)
+	{
+		vertexIndex.buildIndexMinimizers(1, (int)Config::get("minimizer_window"));
+	}
+	else
+	{
+		vertexIndex.countKmers();
+		// freq of every k-mer position is lost after build; dump nothing here
+		vertexIndex.buildIndexUnevenCoverage(MIN_FREQ,
+				Config::get("meta_read_top_kmer_rate"),
+				(int)Config::get("meta_read_filter_kmer_freq"));
+	}
+	auto t2 = clk::now();
+
+	if (!indexOut.empty())
+	{
+		FILE* f = fopen(indexOut.c_str(), "w");
+		fprintf(f, "S sampleRateBits %08x repFreq %zu numKmers %zu keys %zu rep %zu\n",
+				fbits(vertexIndex._sampleRate), vertexIndex._repetitiveFrequency,
+				(size_t)vertexIndex._kmerCounter._numKmers,
+				vertexIndex._kmerIndex.size(), vertexIndex._repetitiveKmers.size());
+		std::vector<std::pair<size_t, std::vector<size_t>>> keys;
+		for (const auto& kv : vertexIndex._kmerIndex.lock_table())
+		{
+			Kmer k = kv.first;
+			std::vector<size_t> pos;
+			for (uint32_t j = 0; j < kv.second.size; ++j) pos.push_back(kv.second.data[j].get());
+			keys.push_back({k.numRepr(), pos});
+		}
+		std::sort(keys.begin(), keys.end());
+		for (auto& kv : keys)
+		{
+			fprintf(f, "K %zx %zu", kv.first, kv.second.size());
+			for (auto p : kv.second) fprintf(f, " %zu", p);
+			fprintf(f, "\n");
+		}
+		std::vector<size_t> rep;
+		for (const auto& kv : vertexIndex._repetitiveKmers.lock_table())
+		{
+			Kmer k = kv.first;
+			rep.push_back(k.numRepr());
+		}
+		std::sort(rep.begin(), rep.end());
+		for (auto r : rep) fprintf(f, "R %zx\n", r);
+		fclose(f);
+	}
+
+	OverlapDetector ovlp(readsContainer, vertexIndex,
+						 (int)Config::get("maximum_jump"),
+						 Parameters::get().minimumOverlap,
+						 (int)Config::get("maximum_overhang"),
+						 /*store alignment*/ false, /*only max*/ true,
+						 /*no div threshold*/ 1.0f,
+						 (bool)Config::get("reads_base_alignment"),
+						 /*partition bad*/ false,
+						 (bool)Config::get("hpc_scoring_on"));
+	OverlapContainer readOverlaps(ovlp, readsContainer);
+	float meanDiv = 0.0f;
+	if (divMode == "assemble")
+	{
+		readOverlaps.estimateOverlaperParameters();
+		readOverlaps.setDivergenceThreshold(
+				(float)Config::get("assemble_ovlp_divergence"),
+				(bool)Config::get("assemble_divergence_relative"));
+		meanDiv = readOverlaps._meanTrueOvlpDiv;
+	}
+	auto t3 = clk::now();
+
+	std::vector<FastaRecord::Id> queries;
+	for (const auto& seq : readsContainer.iterSeqs())
+	{
+		if (seq.id.strand() != rcQueries) queries.push_back(seq.id);
+		if (queryLimit >= 0 && (long)queries.size() >= queryLimit) break;
+	}
+	std::vector<std::vector<OverlapRange>> results(queries.size());
+	std::unordered_map<uint32_t, size_t> slot;
+	for (size_t i = 0; i < queries.size(); ++i) slot[queries[i]._id] = i;
+	std::atomic<size_t> queriedBp(0);
+	std::function<void(const FastaRecord::Id&)> work =
+	[&](const FastaRecord::Id& id)
+	{
+		results[slot[id._id]] = readOverlaps.quickSeqOverlaps(id, maxOverlaps, forceLocal);
+		queriedBp += readsContainer.seqLen(id);
+	};
+	processInParallel(queries, work, threads, false);
+	auto t4 = clk::now();
+
+	size_t total = 0;
+	if (!ovlpOut.empty())
+	{
+		FILE* f = fopen(ovlpOut.c_str(), "w");
+		fprintf(f, "# maxDivBits %08x meanDivBits %08x sampleRateBits %08x\n",
+				fbits(ovlp._maxDivergence), fbits(meanDiv), fbits(vertexIndex._sampleRate));
+		for (auto& vec : results)
+			for (auto& o : vec)
+			{
+				fprintf(f, "%u %d %d %d %u %d %d %d %d %08x\n", o.curId._id, o.curBegin,
+						o.curEnd, o.curLen, o.extId._id, o.extBegin, o.extEnd, o.extLen,
+						o.score, fbits(o.seqDivergence));
+				++total;
+			}
+		fclose(f);
+	}
+	else for (auto& vec : results) total += vec.size();
+
+	auto sec = [](clk::time_point a, clk::time_point b)
+		{ return std::chrono::duration<double>(b - a).count(); };
+	printf("{\"load_s\": %.4f, \"index_s\": %.4f, \"estimate_s\": %.4f, \"overlap_s\": %.4f, "
+		   "\"queried_bp\": %zu, \"queries\": %zu, \"overlaps\": %zu, \"threads\": %d, "
+		   "\"max_div_bits\": \"%08x\"}\n",
+		   sec(t0, t1), sec(t1, t2), sec(t2, t3), sec(t3, t4), (size_t)queriedBp,
+		   queries.size(), total, threads, fbits(ovlp._maxDivergence));
+	return 0;
+}
