@@ -1,0 +1,206 @@
+// C ABI of libflyegpu.so (include/flye_gpu.h): context, read upload, index
+// build/export entry points and the error boundary.  No exception leaves this
+// file; there is no CPU fallback -- without a HIP device fg_create fails.
+#include "fg_ctx.h"
+
+#include <algorithm>
+#include <new>
+
+namespace {
+
+template <class F>
+int guarded(fg_ctx* c, F f)
+{
+	try { f(); return FG_OK; }
+	catch (const FgError& e) { if (c) c->lastError = e.msg; return e.code; }
+	catch (const std::bad_alloc&) { if (c) c->lastError = "host allocation failed"; return FG_ERR_NOMEM; }
+	catch (const std::exception& e) { if (c) c->lastError = e.what(); return FG_ERR_HIP; }
+}
+
+} // namespace
+
+extern "C" {
+
+int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+const char* fg_strerror(int code)
+{
+	switch (code)
+	{
+	case FG_OK: return "ok";
+	case FG_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+	case FG_ERR_HIP: return "HIP runtime error";
+	case FG_ERR_ARG: return "invalid argument";
+	case FG_ERR_STATE: return "invalid call order";
+	case FG_ERR_KMER_TOO_FREQUENT: return "k-mer is too frequent";
+	case FG_ERR_KMER_SIZE: return "unsupported k-mer size";
+	case FG_ERR_UNSUPPORTED: return "flag combination not supported yet";
+	case FG_ERR_NOMEM: return "out of memory";
+	default: return "unknown error";
+	}
+}
+
+const char* fg_last_error(const fg_ctx* ctx) { return ctx ? ctx->lastError.c_str() : ""; }
+
+int fg_create(fg_ctx** out, int device, int kmer_size)
+{
+	if (!out) return FG_ERR_ARG;
+	*out = nullptr;
+	if (kmer_size < 1 || kmer_size > 32) return FG_ERR_KMER_SIZE;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FG_ERR_NO_DEVICE;
+	if (device < 0 || device >= count) return FG_ERR_NO_DEVICE;
+	if (hipSetDevice(device) != hipSuccess) return FG_ERR_NO_DEVICE;
+	fg_ctx* c = new (std::nothrow) fg_ctx;
+	if (!c) return FG_ERR_NOMEM;
+	c->device = device;
+	c->k = kmer_size;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+	{
+		delete c;
+		return FG_ERR_NO_DEVICE;
+	}
+	c->timer.stream = c->stream;
+	*out = c;
+	return FG_OK;
+}
+
+void fg_destroy(fg_ctx* ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	delete ctx;
+}
+
+int fg_set_reads(fg_ctx* c, uint32_t n, const uint64_t* words, const uint64_t* word_off,
+				 const int32_t* len, uint32_t first_seq_id)
+{
+	if (!c || (n && (!words || !word_off || !len))) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		if ((u64)first_seq_id + 2ULL * n > 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "sequence ids overflow uint32"};
+		c->indexBuilt = false;
+		c->nReads = n;
+		c->firstId = first_seq_id;
+		c->totalWords = n ? word_off[n] : 0;
+		c->hLen.assign(len, len + n);
+		c->hKmerOff.assign(n + 1, 0);
+		c->totalBases = 0;
+		c->maxLen = 0;
+		for (u32 i = 0; i < n; ++i)
+		{
+			if (len[i] < 0) throw FgError{FG_ERR_ARG, "negative read length"};
+			if ((u64)(len[i] + 31) / 32 > word_off[i + 1] - word_off[i])
+				throw FgError{FG_ERR_ARG, "word_off does not cover read " + std::to_string(i)};
+			c->hKmerOff[i + 1] = c->hKmerOff[i] + (u64)std::max(0, len[i] - c->k);
+			c->totalBases += len[i];
+			c->maxLen = std::max(c->maxLen, len[i]);
+		}
+		c->totalKmers = c->hKmerOff[n];
+		c->dWords.alloc(c->totalWords + 2);
+		c->dWordOff.alloc(n + 1);
+		c->dLen.alloc(n);
+		c->dKmerOff.alloc(n + 1);
+		hipStream_t s = c->stream;
+		HIP_CHECK(hipMemsetAsync(c->dWords.p + c->totalWords, 0, 16, s));
+		if (n)
+		{
+			HIP_CHECK(hipMemcpyAsync(c->dWords.p, words, c->totalWords * 8, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(c->dWordOff.p, word_off, (n + 1) * 8ULL, hipMemcpyHostToDevice, s));
+			HIP_CHECK(hipMemcpyAsync(c->dLen.p, len, n * 4ULL, hipMemcpyHostToDevice, s));
+		}
+		HIP_CHECK(hipMemcpyAsync(c->dKmerOff.p, c->hKmerOff.data(), (n + 1) * 8ULL, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	});
+}
+
+int fg_build_index_solid(fg_ctx* c, int32_t min_freq, float select_rate, int32_t tandem_freq,
+						 float repeat_rate, float sample_rate_init, struct fg_index_stats* out)
+{
+	if (!c || !out) return FG_ERR_ARG;
+	if (!(select_rate >= 0.0f && select_rate < 1.0f)) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgBuildIndexSolid(c, min_freq, select_rate, tandem_freq, repeat_rate, sample_rate_init, out);
+	});
+}
+
+int fg_build_index_minimizers(fg_ctx* c, int32_t min_coverage, int32_t window, float repeat_rate,
+							  struct fg_index_stats* out)
+{
+	if (!c || !out) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgBuildIndexMinimizers(c, min_coverage, window, repeat_rate, out);
+	});
+}
+
+int fg_clear_index(fg_ctx* c)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		c->indexBuilt = false;
+		c->dKeys.release(); c->dKeyOff.release(); c->dEntries.release(); c->dRepKeys.release();
+		c->dTable.release(); c->dIndexedBits.release();
+		c->nKeys = c->nEntries = c->nRep = c->tableSlots = 0;
+	});
+}
+
+int fg_export_index(fg_ctx* c, uint64_t* n_keys, uint64_t* n_entries, uint64_t* n_repetitive,
+					uint64_t* keys, uint64_t* key_off, uint64_t* entries, uint64_t* repetitive_keys)
+{
+	if (!c || !n_keys || !n_entries || !n_repetitive) return FG_ERR_ARG;
+	if (!c->indexBuilt) return FG_ERR_STATE;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		*n_keys = c->nKeys; *n_entries = c->nEntries; *n_repetitive = c->nRep;
+		hipStream_t s = c->stream;
+		if (keys && c->nKeys) HIP_CHECK(hipMemcpyAsync(keys, c->dKeys.p, c->nKeys * 8, hipMemcpyDeviceToHost, s));
+		if (key_off) HIP_CHECK(hipMemcpyAsync(key_off, c->dKeyOff.p, (c->nKeys + 1) * 8, hipMemcpyDeviceToHost, s));
+		if (entries && c->nEntries) HIP_CHECK(hipMemcpyAsync(entries, c->dEntries.p, c->nEntries * 8, hipMemcpyDeviceToHost, s));
+		if (repetitive_keys && c->nRep) HIP_CHECK(hipMemcpyAsync(repetitive_keys, c->dRepKeys.p, c->nRep * 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	});
+}
+
+int fg_overlaps(fg_ctx* c, const struct fg_detector_params* p, const uint32_t* query_ids,
+				uint32_t n_queries, int32_t max_overlaps, uint8_t force_local,
+				struct fg_overlap_batch* out)
+{
+	if (!c || !p || !out || (n_queries && !query_ids)) return FG_ERR_ARG;
+	memset(out, 0, sizeof(*out));
+	if (!c->indexBuilt) return FG_ERR_STATE;
+	if (p->keep_alignment || p->partition_bad_mappings || !p->only_max_ext) return FG_ERR_UNSUPPORTED;
+	if (p->max_jump <= 0 || p->min_overlap <= 0 || max_overlaps < 0) return FG_ERR_ARG;
+	for (u32 i = 0; i < n_queries; ++i)
+		if (query_ids[i] < c->firstId || query_ids[i] - c->firstId >= 2 * c->nReads) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgOverlaps(c, p, query_ids, n_queries, max_overlaps, force_local, out);
+	});
+}
+
+void fg_release_batch(struct fg_overlap_batch* b)
+{
+	if (!b) return;
+	delete (BatchOwner*)b->owner_;
+	memset(b, 0, sizeof(*b));
+}
+
+int fg_kernel_times(fg_ctx* c, struct fg_kernel_time* out, int max_entries)
+{
+	if (!c) return FG_ERR_ARG;
+	int n = (int)c->timer.last.size();
+	for (int i = 0; i < n && i < max_entries; ++i) out[i] = c->timer.last[i];
+	return n;
+}
+
+} // extern "C"

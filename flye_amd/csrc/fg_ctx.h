@@ -1,0 +1,245 @@
+// Internal context of libflyegpu.so (host side) + device helpers shared by the
+// kernels.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/flye_gpu.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int32_t i32;
+
+#define FG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
+#define FG_CNT_BITS 24
+#define FG_CNT_MASK 0xFFFFFFu
+#define FG_CNT_REPETITIVE 0xFFFFFFu	// slot marks a k-mer of _repetitiveKmers
+
+struct FgError { int code; std::string msg; };
+
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	throw FgError{FG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + \
+	" (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"}; } } while (0)
+
+// --- device buffer -----------------------------------------------------------
+template <class T>
+struct DevBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	DevBuf() {}
+	DevBuf(const DevBuf&) = delete;
+	DevBuf& operator=(const DevBuf&) = delete;
+	~DevBuf() { release(); }
+	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+	void alloc(size_t count)
+	{
+		release();
+		if (count == 0) count = 1;
+		hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+		if (e != hipSuccess)
+			throw FgError{FG_ERR_NOMEM, "hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e)};
+		n = count;
+	}
+	// grow-only (keeps capacity between batches)
+	void reserve(size_t count) { if (count > n) alloc(count + count / 8); }
+	size_t bytes() const { return n * sizeof(T); }
+};
+
+// --- per-kernel timing with HIP events on the library stream -------------------
+struct KernelTimer {
+	struct Ev { const char* name; hipEvent_t a, b; };
+	std::vector<Ev> evs;
+	std::vector<hipEvent_t> pool;
+	hipStream_t stream = nullptr;
+	bool enabled = true;
+	std::vector<fg_kernel_time> last;
+
+	hipEvent_t get()
+	{
+		if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+		hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+	}
+	size_t begin(const char* name)
+	{
+		if (!enabled) return 0;
+		Ev ev{name, get(), get()};
+		HIP_CHECK(hipEventRecord(ev.a, stream));
+		evs.push_back(ev);
+		return evs.size() - 1;
+	}
+	void end(size_t id)
+	{
+		if (!enabled) return;
+		HIP_CHECK(hipEventRecord(evs[id].b, stream));
+	}
+	// after a stream sync: fold into per-name sums
+	void collect()
+	{
+		last.clear();
+		std::vector<std::string> order;
+		std::map<std::string, size_t> idx;
+		for (auto& ev : evs)
+		{
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, ev.a, ev.b));
+			auto it = idx.find(ev.name);
+			if (it == idx.end())
+			{
+				idx[ev.name] = last.size();
+				last.push_back(fg_kernel_time{ev.name, 0.0, 0});
+				it = idx.find(ev.name);
+			}
+			last[it->second].seconds += ms * 1e-3;
+			last[it->second].launches += 1;
+			pool.push_back(ev.a); pool.push_back(ev.b);
+		}
+		evs.clear();
+	}
+	~KernelTimer() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+struct ScopedK {
+	KernelTimer& t; size_t id;
+	ScopedK(KernelTimer& t_, const char* name) : t(t_), id(t_.begin(name)) {}
+	~ScopedK() { try { t.end(id); } catch (...) {} }
+};
+
+struct fg_ctx {
+	int device = 0;
+	int k = 17;
+	hipStream_t stream = nullptr;
+	std::string lastError;
+	KernelTimer timer;
+
+	// reads (the index container == the query container for now)
+	u32 nReads = 0;
+	u32 firstId = 0;
+	u64 totalWords = 0, totalBases = 0, totalKmers = 0;
+	i32 maxLen = 0;
+	std::vector<i32> hLen;
+	std::vector<u64> hKmerOff;
+	DevBuf<u64> dWords;		// +2 padding words
+	DevBuf<u64> dWordOff;	// n+1
+	DevBuf<i32> dLen;		// n
+	DevBuf<u64> dKmerOff;	// n+1 prefix of max(len-k,0)
+
+	// index
+	bool indexBuilt = false;
+	float sampleRate = 1.0f;
+	u64 nKeys = 0, nEntries = 0, nRep = 0, tableSlots = 0;
+	DevBuf<u64> dKeys;		// ascending canonical k-mers of _kmerIndex (incl. empty lists)
+	DevBuf<u64> dKeyOff;	// nKeys+1
+	DevBuf<u64> dEntries;	// (record<<32 | pos), ascending per key
+	DevBuf<u64> dRepKeys;	// ascending
+	DevBuf<ulonglong2> dTable;	// {key, off<<24 | cnt}
+	DevBuf<u32> dIndexedBits;	// one bit per forward k-mer position: contributes an entry
+
+	// overlap-stage scratch (grow-only)
+	DevBuf<u32> dQuery;			// query record indices
+	DevBuf<u64> dQKmerOff;		// per query prefix of k-mer counts
+	DevBuf<u64> dProbe;			// per query k-mer: table value (0 = miss)
+	DevBuf<u64> dHitOff;		// per query hit offsets (nq+1)
+	DevBuf<u64> dFiltOff;		// per query repetitive-position offsets (nq+1)
+	DevBuf<i32> dFiltPos;
+	DevBuf<u64> dHitKey;		// extId<<32 | curPos
+	DevBuf<u32> dHitVal;		// extPos
+	DevBuf<i32> dScore, dBack, dOrder;
+	DevBuf<int4> dCand;
+	DevBuf<u64> dGroupStart;	// group boundaries (indices into hits)
+	DevBuf<u32> dGroupQuery;
+	DevBuf<u32> dTmp32;
+	DevBuf<u64> dTmp64;
+	DevBuf<u64> dCounters;
+
+	~fg_ctx() { if (stream) (void)hipStreamDestroy(stream); }
+};
+
+// --- device helpers ----------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ u64 fg_mix(u64 x)
+{
+	x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+	x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+	return x;
+}
+
+// splitmix64 finaliser = Kmer::hash() (reference src/sequence/kmer.h:91-98)
+__device__ __forceinline__ u64 fg_kmer_hash(u64 x)
+{
+	u64 z = (x += 0x9E3779B97F4A7C15ULL);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+// 2k bits of the packed forward read starting at base q (base q in bits 0-1).
+// `w` points at the read's first word; the caller guarantees q + k <= len.
+__device__ __forceinline__ u64 fg_chunk(const u64* __restrict__ w, i32 q, int k)
+{
+	const int sh = (q & 31) * 2;
+	u64 lo = w[q >> 5] >> sh;
+	if (sh + 2 * k > 64) lo |= w[(q >> 5) + 1] << (64 - sh);
+	return (k == 32) ? lo : (lo & ((1ULL << (2 * k)) - 1));
+}
+
+// reverse the order of the k 2-bit groups: packed chunk -> Kmer repr (first
+// base most significant, kmer.h:32-36)
+__device__ __forceinline__ u64 fg_rev2(u64 x, int k)
+{
+	u64 r = __brevll(x);
+	r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+	return r >> (64 - 2 * k);
+}
+
+// forward / reverse-complement representation of the k-mer at forward position
+// q; rc repr is simply the complemented packed chunk (kmer.h:39-52)
+__device__ __forceinline__ void fg_kmer_pair(const u64* __restrict__ w, i32 q, int k, u64& fw, u64& rv)
+{
+	const u64 x = fg_chunk(w, q, k);
+	const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+	fw = fg_rev2(x, k);
+	rv = ~x & mask;
+}
+
+// probe: returns the slot value (off<<24|cnt) or 0 when absent
+__device__ __forceinline__ u64 fg_probe(const ulonglong2* __restrict__ table, u64 mask, u64 key)
+{
+	u64 h = fg_mix(key) & mask;
+	while (true)
+	{
+		ulonglong2 s = table[h];
+		if (s.x == key) return s.y;
+		if (s.x == FG_EMPTY_KEY) return 0;
+		h = (h + 1) & mask;
+	}
+}
+
+#endif // __HIPCC__
+
+struct BatchOwner {
+	std::vector<u64> queryOff, statOff;
+	std::vector<fg_overlap_rec> recs;
+	std::vector<float> stats;
+};
+
+// one primary overlap candidate as the device hands it to the host shim
+struct PrimRec {
+	u32 query;		// index into the batch
+	u32 extId;
+	i32 curBegin, curEnd, extBegin, extEnd, extLen, score, chainLength, filtered;
+	i32 editDistance, hpcLenCur, hpcLenExt;
+};
+
+// implemented in fg_index.hip / fg_overlap.hip
+void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, fg_index_stats* st);
+void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
+void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
+				uint8_t forceLocal, fg_overlap_batch* out);

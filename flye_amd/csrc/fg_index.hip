@@ -1,0 +1,763 @@
+// Index build on the device: exact canonical k-mer counting, per-read solid
+// k-mer selection, minimizer sketch, and the k-mer -> sorted position list index
+// (CSR + open-addressing probe table).
+//
+// Behaviour restated from the reference (Flye 2.8.1), file:line in each kernel:
+//   KmerCounter::count/getFreq          src/sequence/vertex_index.cpp:499-616
+//   VertexIndex::yieldFrequentKmers     src/sequence/vertex_index.cpp:316-358
+//   buildIndexUnevenCoverage            src/sequence/vertex_index.cpp:25-125
+//   filterFrequentKmers                 src/sequence/vertex_index.cpp:173-212
+//   buildIndexMinimizers                src/sequence/vertex_index.cpp:389-483
+//   yieldMinimizers                     src/sequence/kmer.h:206-262
+//
+// Design (MI355X-first, not the reference's cuckoo-map-of-vectors):
+//   * counting: one u32 counter per possible k-mer, direct addressed (4^k * 4 B =
+//     68.7 GB at k = 17, sized for 288 GB HBM), one global atomic per k-mer, no CAS
+//     loop, no overflow map, exact; freed after the build like _kmerCounter.clear();
+//   * selection threshold: one workgroup per read, LDS histogram radix-select;
+//   * index: accepted (k-mer, position) pairs are emitted unordered, ordered by two
+//     stable LSD radix sorts (rocPRIM device primitive) and cut into a CSR by a
+//     head-flag scan; lookups go through a linear-probing table of 16-byte slots
+//     {key, offset<<24|count} at load <= 0.5, one dwordx4 load per probe.
+#include "fg_ctx.h"
+
+#include <rocprim/rocprim.hpp>
+
+#define WG 256
+
+namespace {
+
+// ---------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ T block_sum(T v, T* sh /* >= WG/64 */)
+{
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+	const int w = threadIdx.x >> 6;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0) sh[w] = v;
+	__syncthreads();
+	T t = 0;
+	if (threadIdx.x == 0) for (int i = 0; i < WG / 64; ++i) t += sh[i];
+	return t;	// valid on thread 0
+}
+
+// vertex_index.cpp:520-558: one increment per canonical k-mer of every forward read
+__global__ void k_count(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+						const i32* __restrict__ len, int k, u32* __restrict__ counts,
+						unsigned long long* __restrict__ distinct)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	u32 local = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 cn = fw < rv ? fw : rv;
+		local += (atomicAdd(&counts[cn], 1u) == 0u);
+	}
+	u32 t = block_sum(local, sh);
+	if (threadIdx.x == 0 && t) atomicAdd(distinct, (unsigned long long)t);
+}
+
+// KmerCounter::getFreq for every k-mer position (vertex_index.cpp:326-333)
+__global__ void k_freq(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+					   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+					   const u32* __restrict__ counts, u32* __restrict__ freq)
+{
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	u32* f = freq + kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		f[p] = counts[fw < rv ? fw : rv];
+	}
+}
+
+// vertex_index.cpp:336-344: threshold = frequency at rank (size_t)(selectRate * n)
+// of the descending order; all k-mers with freq >= threshold are kept.
+#define HBINS 2048
+__global__ void k_threshold(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+							const u32* __restrict__ freq, float selectRate, u32* __restrict__ thr)
+{
+	__shared__ u32 hist[HBINS];
+	__shared__ u32 shThr;
+	__shared__ u32 shCnt[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	if (nk <= 0) { if (threadIdx.x == 0) thr[r] = 0; return; }
+	const u32* f = freq + kmerOff[r];
+	for (int i = threadIdx.x; i < HBINS; i += WG) hist[i] = 0;
+	__syncthreads();
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		u32 v = f[p];
+		atomicAdd(&hist[v < HBINS - 1 ? v : HBINS - 1], 1u);
+	}
+	__syncthreads();
+	const u64 maxKmers = (u64)(selectRate * (float)(u64)nk);	// float multiply, truncation (:339)
+	if (threadIdx.x == 0)
+	{
+		// largest v with #(freq >= v) > maxKmers
+		u64 ge = (u64)nk;	// #(freq >= 0)
+		u32 v = 0;
+		while (v < HBINS - 1 && ge - hist[v] > maxKmers) { ge -= hist[v]; ++v; }
+		shThr = v;
+	}
+	__syncthreads();
+	if (shThr < HBINS - 1) { if (threadIdx.x == 0) thr[r] = shThr; return; }
+	// rare: the threshold lies in the overflow bin -> bisect on the exact values
+	u32 lo = HBINS - 1, hi = 0xFFFFFFFFu;	// invariant: #(f >= lo) > maxKmers
+	while (lo < hi)
+	{
+		const u32 mid = lo + (u32)(((u64)hi - lo + 1) / 2);
+		u32 c = 0;
+		for (i32 p = threadIdx.x; p < nk; p += WG) c += (f[p] >= mid);
+		u32 t = block_sum(c, shCnt);
+		if (threadIdx.x == 0) shThr = t;
+		__syncthreads();
+		if ((u64)shThr > maxKmers) lo = mid; else hi = mid - 1;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) thr[r] = lo;
+}
+
+// flags: bit0 selected (freq >= per-read threshold), bit1 tandem candidate
+__global__ void k_mark(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+					   const u32* __restrict__ freq, const u32* __restrict__ thr, i32 tandemFreq,
+					   uint8_t* __restrict__ flags, unsigned long long* __restrict__ nCand)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	if (nk <= 0) return;
+	const u32* f = freq + kmerOff[r];
+	uint8_t* fl = flags + kmerOff[r];
+	const u32 t = thr[r];
+	u32 c = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		const u32 v = f[p];
+		uint8_t b = v >= t;
+		if (b && tandemFreq > 0 && v > (u32)tandemFreq) { b |= 2; ++c; }
+		fl[p] = b;
+	}
+	u32 tot = block_sum(c, sh);
+	if (threadIdx.x == 0 && tot) atomicAdd(nCand, (unsigned long long)tot);
+}
+
+// vertex_index.cpp:346-355: k-mers occurring > tandemFreq times inside ONE read are
+// dropped.  Only candidates (global freq > tandemFreq) can qualify; they are
+// counted exactly in a (read, k-mer) keyed table.
+__global__ void k_tandem_insert(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+								const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+								const uint8_t* __restrict__ flags, u64* __restrict__ tkeys,
+								u32* __restrict__ tcnt, u64 tmask)
+{
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const uint8_t* fl = flags + kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		if (!(fl[p] & 2)) continue;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 key = ((u64)r << 34) | (fw < rv ? fw : rv);
+		u64 h = fg_mix(key) & tmask;
+		while (true)
+		{
+			u64 old = atomicCAS((unsigned long long*)&tkeys[h], (unsigned long long)FG_EMPTY_KEY,
+								(unsigned long long)key);
+			if (old == FG_EMPTY_KEY || old == key) { atomicAdd(&tcnt[h], 1u); break; }
+			h = (h + 1) & tmask;
+		}
+	}
+}
+
+__global__ void k_tandem_apply(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+							   uint8_t* __restrict__ flags, const u64* __restrict__ tkeys,
+							   const u32* __restrict__ tcnt, u64 tmask, i32 tandemFreq)
+{
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	uint8_t* fl = flags + kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		if (!(fl[p] & 2)) continue;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 key = ((u64)r << 34) | (fw < rv ? fw : rv);
+		u64 h = fg_mix(key) & tmask;
+		while (tkeys[h] != key) h = (h + 1) & tmask;
+		if (tcnt[h] > (u32)tandemFreq) fl[p] = 0;
+	}
+}
+
+// bit0 := accepted for the index (selected, not tandem, freq >= minFreq)
+__global__ void k_accept(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+						 const u32* __restrict__ freq, i32 minFreq, uint8_t* __restrict__ flags,
+						 unsigned long long* __restrict__ nAcc)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	if (nk <= 0) return;
+	const u32* f = freq + kmerOff[r];
+	uint8_t* fl = flags + kmerOff[r];
+	u32 c = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		uint8_t b = (fl[p] & 1) && f[p] >= (u32)minFreq;
+		fl[p] = b;
+		c += b;
+	}
+	u32 tot = block_sum(c, sh);
+	if (threadIdx.x == 0 && tot) atomicAdd(nAcc, (unsigned long long)tot);
+}
+
+// ---- minimizer sketch (kmer.h:206-262) ------------------------------------------
+// The sketch equals "the sequence of distinct deque fronts".  Whenever hash[p] is
+// strictly below the w previous hashes (or p == 0) the deque collapses to [p]
+// whatever came before (a sync point), so the stretch up to the next sync point
+// is an independent piece: sync points are found in parallel, then one lane runs
+// the literal deque loop over one piece.
+#define MAXW 64
+__global__ void k_minimizers(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+							 const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k, int w,
+							 u64* __restrict__ hashes /* per k-mer position scratch */,
+							 uint8_t* __restrict__ flags, unsigned long long* __restrict__ nAcc)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	if (nk <= 0) return;
+	const u64* wd = words + wordOff[r];
+	u64* hs = hashes + kmerOff[r];
+	uint8_t* fl = flags + kmerOff[r];
+	if (w == 1)
+	{
+		u32 c = 0;
+		for (i32 p = threadIdx.x; p < nk; p += WG) { fl[p] = 1; ++c; }
+		u32 tot = block_sum(c, sh);
+		if (threadIdx.x == 0) atomicAdd(nAcc, (unsigned long long)tot);
+		return;
+	}
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		u64 fw, rv;
+		fg_kmer_pair(wd, p, k, fw, rv);
+		hs[p] = fg_kmer_hash(fw < rv ? fw : rv);
+		fl[p] = 0;
+	}
+	__syncthreads();
+	u32 c = 0;
+	for (i32 p0 = threadIdx.x; p0 < nk; p0 += WG)
+	{
+		// is p0 a sync point?
+		const u64 h0 = hs[p0];
+		bool sync = true;
+		for (i32 j = p0 - 1; j >= 0 && j >= p0 - w; --j)
+			if (hs[j] <= h0) { sync = false; break; }
+		if (!sync) continue;
+		// literal deque from an empty state, until the next sync point
+		i32 qpos[MAXW + 2]; u64 qh[MAXW + 2];
+		int head = 0, tail = 0;	// ring of capacity MAXW+2
+		const int CAP = MAXW + 2;
+		i32 lastEmit = -1;
+		for (i32 p = p0; p < nk; ++p)
+		{
+			const u64 h = hs[p];
+			if (p > p0)
+			{
+				// stop at the next sync point (it starts its own piece)
+				bool s2 = true;
+				for (i32 j = p - 1; j >= 0 && j >= p - w; --j)
+					if (hs[j] <= h) { s2 = false; break; }
+				if (s2) break;
+			}
+			while (tail != head && qh[(tail + CAP - 1) % CAP] > h) tail = (tail + CAP - 1) % CAP;
+			qpos[tail] = p; qh[tail] = h; tail = (tail + 1) % CAP;
+			if (qpos[head] <= p - w)
+			{
+				while (qpos[head] <= p - w) head = (head + 1) % CAP;
+				while ((tail + CAP - head) % CAP >= 2 && qh[head] == qh[(head + 1) % CAP]) head = (head + 1) % CAP;
+			}
+			if (lastEmit != qpos[head])
+			{
+				lastEmit = qpos[head];
+				if (!fl[lastEmit]) { fl[lastEmit] = 1; ++c; }
+			}
+		}
+	}
+	u32 tot = block_sum(c, sh);
+	if (threadIdx.x == 0 && tot) atomicAdd(nAcc, (unsigned long long)tot);
+}
+
+// canonical-orientation entry of every accepted position (vertex_index.cpp:76-85):
+// value = (record << posBits) | position with record = 2*read (+1 if the k-mer was
+// flipped, position mirrored)
+__global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+					   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+					   const uint8_t* __restrict__ flags, int posBits, u64* __restrict__ ecanon,
+					   u64* __restrict__ evalue, unsigned long long* __restrict__ cursor)
+{
+	const u32 r = blockIdx.x;
+	const i32 L = len[r];
+	const i32 nk = L - k;
+	const u64* w = words + wordOff[r];
+	const uint8_t* fl = flags + kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		if (!fl[p]) continue;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const bool flip = rv < fw;
+		const u64 slot = atomicAdd(cursor, 1ULL);
+		ecanon[slot] = flip ? rv : fw;
+		evalue[slot] = ((u64)(2 * r + (flip ? 1 : 0)) << posBits) | (u64)(flip ? L - p - k : p);
+	}
+}
+
+__global__ void k_heads(const u64* __restrict__ c, u64 n, u32* __restrict__ flag)
+{
+	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || c[i] != c[i - 1]) ? 1u : 0u;
+}
+
+__global__ void k_keys(const u64* __restrict__ c, u64 n, const u32* __restrict__ flag,
+					   const u32* __restrict__ inc, u64* __restrict__ ukeys, u64* __restrict__ kstart)
+{
+	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
+	if (i < n && flag[i]) { ukeys[inc[i] - 1] = c[i]; kstart[inc[i] - 1] = i; }
+}
+
+// filterFrequentKmers sums (vertex_index.cpp:175-184)
+__global__ void k_capstats(const u64* __restrict__ kstart, u64 nKeys, i32 minCoverage,
+						   unsigned long long* __restrict__ out /* total, unique */)
+{
+	__shared__ u64 sh[WG / 64];
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	u64 cap = 0, uq = 0;
+	if (j < nKeys)
+	{
+		cap = kstart[j + 1] - kstart[j];
+		if (cap >= (u64)minCoverage) uq = 1; else cap = 0;
+	}
+	u64 t = block_sum(cap, sh);
+	if (threadIdx.x == 0 && t) atomicAdd(&out[0], (unsigned long long)t);
+	u64 u = block_sum(uq, sh);
+	if (threadIdx.x == 0 && u) atomicAdd(&out[1], (unsigned long long)u);
+}
+
+// vertex_index.cpp:189-202 (repetitive keys leave the index), :70-71 (entries are
+// written only when minFreq <= freq <= repFreq), :370-373 (capacity limit)
+__global__ void k_classify(const u64* __restrict__ ukeys, const u64* __restrict__ kstart, u64 nKeys,
+						   u64 repFreq, const u32* __restrict__ counts /* null in minimizer mode */,
+						   u32* __restrict__ isRep, u32* __restrict__ keep, u64* __restrict__ size,
+						   u32* __restrict__ err)
+{
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	if (j >= nKeys) return;
+	const u64 cap = kstart[j + 1] - kstart[j];
+	const bool rep = cap > repFreq;
+	bool filled = !rep;
+	if (filled && counts) filled = (u64)counts[ukeys[j]] <= repFreq;
+	isRep[j] = rep;
+	keep[j] = !rep;
+	size[j] = filled ? cap : 0;
+	if (!rep && cap + 1 > (u64)(32 * 1024 * 1024 / 5)) *err = 1;
+}
+
+__global__ void k_finalize(const u64* __restrict__ ukeys, u64 nKeys, const u32* __restrict__ isRep,
+						   const u32* __restrict__ repIdx, const u32* __restrict__ keepIdx,
+						   const u64* __restrict__ off, u64* __restrict__ keys, u64* __restrict__ keyOff,
+						   u64* __restrict__ repKeys)
+{
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	if (j >= nKeys) return;
+	if (isRep[j]) repKeys[repIdx[j]] = ukeys[j];
+	else { keys[keepIdx[j]] = ukeys[j]; keyOff[keepIdx[j]] = off[j]; }
+}
+
+__global__ void k_entries(const u64* __restrict__ evalue, u64 n, const u32* __restrict__ inc,
+						  const u64* __restrict__ kstart, const u64* __restrict__ size,
+						  const u64* __restrict__ off, int posBits, u64* __restrict__ entries)
+{
+	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	const u32 j = inc[i] - 1;
+	if (size[j] == 0) return;
+	const u64 v = evalue[i];
+	entries[off[j] + (i - kstart[j])] = ((v >> posBits) << 32) | (v & ((1ULL << posBits) - 1));
+}
+
+__global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restrict__ keyOff, u64 nKeys,
+							   const u64* __restrict__ repKeys, u64 nRep, ulonglong2* __restrict__ table,
+							   u64 mask)
+{
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	u64 key, val;
+	if (j < nKeys)
+	{
+		const u64 cnt = keyOff[j + 1] - keyOff[j];
+		if (cnt == 0) return;	// an empty list behaves like an absent key (overlap.cpp:183)
+		key = keys[j]; val = (keyOff[j] << FG_CNT_BITS) | cnt;
+	}
+	else if (j < nKeys + nRep) { key = repKeys[j - nKeys]; val = FG_CNT_REPETITIVE; }
+	else return;
+	u64 h = fg_mix(key) & mask;
+	while (true)
+	{
+		u64 old = atomicCAS((unsigned long long*)&table[h].x, (unsigned long long)FG_EMPTY_KEY,
+							(unsigned long long)key);
+		if (old == FG_EMPTY_KEY) { table[h].y = val; break; }
+		h = (h + 1) & mask;
+	}
+}
+
+// one bit per forward k-mer position: does this position own an index entry?
+// (lets the seed collector skip the trivial self hit, overlap.cpp:188-190,
+// without searching the list)
+__global__ void k_indexed_bits(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+							   const uint8_t* __restrict__ flags, const ulonglong2* __restrict__ table,
+							   u64 mask, u32* __restrict__ bits)
+{
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const uint8_t* fl = flags + kmerOff[r];
+	const u64 base = kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		if (!fl[p]) continue;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 v = fg_probe(table, mask, fw < rv ? fw : rv);
+		if (v != 0 && (v & FG_CNT_MASK) != FG_CNT_REPETITIVE)
+			atomicOr(&bits[(base + p) >> 5], 1u << ((base + p) & 31));
+	}
+}
+
+// ---- host helpers -----------------------------------------------------------------
+struct Prim {
+	fg_ctx* c;
+	DevBuf<char> tmp;
+	void sortPairs(u64* kin, u64* kout, u64* vin, u64* vout, u64 n, int bits)
+	{
+		if (n == 0) return;
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, c->stream));
+		tmp.reserve(bytes);
+		HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, c->stream));
+	}
+	template <class T>
+	void incScan(const T* in, T* out, u64 n)
+	{
+		if (n == 0) return;
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), c->stream));
+		tmp.reserve(bytes);
+		HIP_CHECK(rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::plus<T>(), c->stream));
+	}
+	template <class T>
+	void excScan(const T* in, T* out, u64 n)
+	{
+		if (n == 0) return;
+		size_t bytes = 0;
+		HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+		tmp.reserve(bytes);
+		HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
+	}
+};
+
+template <class T>
+T fetch(fg_ctx* c, const T* dptr)
+{
+	T v;
+	HIP_CHECK(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	return v;
+}
+
+int bitsFor(u64 v) { int b = 1; while ((1ULL << b) <= v && b < 63) ++b; return b; }
+unsigned gridFor(u64 n) { return (unsigned)((n + WG - 1) / WG); }
+
+// common tail of both build modes: (canon, value) pairs -> CSR + probe table
+void finishIndex(fg_ctx* c, Prim& prim, DevBuf<u64>& ecanon, DevBuf<u64>& evalue, u64 E, int posBits,
+				 i32 minCoverage, float repeatRate, const u32* counts, const uint8_t* flags,
+				 fg_index_stats* st)
+{
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 n = c->nReads;
+	DevBuf<u64> ecanon2, evalue2;
+	ecanon2.alloc(E); evalue2.alloc(E);
+	const int valBits = posBits + bitsFor(2ULL * n);
+	{
+		ScopedK t(c->timer, "radix_sort_pairs(rocprim)");
+		prim.sortPairs(evalue.p, evalue2.p, ecanon.p, ecanon2.p, E, valBits);
+		prim.sortPairs(ecanon2.p, ecanon.p, evalue2.p, evalue.p, E, 2 * k);
+	}
+	ecanon2.release(); evalue2.release();
+
+	// run-length encode the sorted k-mers
+	DevBuf<u32> flag, inc;
+	flag.alloc(E); inc.alloc(E);
+	u64 nKeys = 0;
+	if (E)
+	{
+		{ ScopedK t(c->timer, "k_heads"); hipLaunchKernelGGL(k_heads, gridFor(E), WG, 0, s, ecanon.p, E, flag.p); }
+		{ ScopedK t(c->timer, "scan(rocprim)"); prim.incScan(flag.p, inc.p, E); }
+		nKeys = fetch(c, inc.p + (E - 1));
+	}
+	DevBuf<u64> ukeys, kstart;
+	ukeys.alloc(nKeys); kstart.alloc(nKeys + 1);
+	if (E)
+	{
+		ScopedK t(c->timer, "k_keys");
+		hipLaunchKernelGGL(k_keys, gridFor(E), WG, 0, s, ecanon.p, E, flag.p, inc.p, ukeys.p, kstart.p);
+	}
+	HIP_CHECK(hipMemcpyAsync(kstart.p + nKeys, &E, 8, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	flag.release();
+
+	// filterFrequentKmers: two integer sums on the device, the two float
+	// operations on the host exactly as vertex_index.cpp:185-186 writes them
+	DevBuf<unsigned long long> sums;
+	sums.alloc(2);
+	HIP_CHECK(hipMemsetAsync(sums.p, 0, 16, s));
+	if (nKeys)
+	{
+		ScopedK t(c->timer, "k_capstats");
+		hipLaunchKernelGGL(k_capstats, gridFor(nKeys), WG, 0, s, kstart.p, nKeys, minCoverage, sums.p);
+	}
+	unsigned long long hs[2];
+	HIP_CHECK(hipMemcpyAsync(hs, sums.p, 16, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	size_t totalKmers = hs[0], uniqueKmers = hs[1];
+	float meanFrequency = (float)totalKmers / (uniqueKmers + 1);
+	size_t repFreq = repeatRate * meanFrequency;
+	st->mean_frequency = meanFrequency;
+	st->repetitive_frequency = repFreq;
+
+	DevBuf<u32> isRep, keep, repIdx, keepIdx, err;
+	DevBuf<u64> size, off;
+	isRep.alloc(nKeys + 1); keep.alloc(nKeys + 1); repIdx.alloc(nKeys + 1); keepIdx.alloc(nKeys + 1);
+	size.alloc(nKeys + 1); off.alloc(nKeys + 1); err.alloc(1);
+	HIP_CHECK(hipMemsetAsync(err.p, 0, 4, s));
+	// one extra zero element so that the exclusive scans also yield the totals
+	HIP_CHECK(hipMemsetAsync(isRep.p + nKeys, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(keep.p + nKeys, 0, 4, s));
+	HIP_CHECK(hipMemsetAsync(size.p + nKeys, 0, 8, s));
+	if (nKeys)
+	{
+		ScopedK t(c->timer, "k_classify");
+		hipLaunchKernelGGL(k_classify, gridFor(nKeys), WG, 0, s, ukeys.p, kstart.p, nKeys, (u64)repFreq, counts,
+						   isRep.p, keep.p, size.p, err.p);
+	}
+	{
+		ScopedK t(c->timer, "scan(rocprim)");
+		prim.excScan(isRep.p, repIdx.p, nKeys + 1);
+		prim.excScan(keep.p, keepIdx.p, nKeys + 1);
+		prim.excScan(size.p, off.p, nKeys + 1);
+	}
+	const u64 nRep = fetch(c, repIdx.p + nKeys);
+	const u64 nKeep = fetch(c, keepIdx.p + nKeys);
+	const u64 nEnt = fetch(c, off.p + nKeys);
+	if (fetch(c, err.p)) throw FgError{FG_ERR_KMER_TOO_FREQUENT, "k-mer is too frequent"};
+
+	c->dKeys.alloc(nKeep); c->dKeyOff.alloc(nKeep + 1); c->dEntries.alloc(nEnt); c->dRepKeys.alloc(nRep);
+	if (nKeys)
+	{
+		ScopedK t(c->timer, "k_finalize");
+		hipLaunchKernelGGL(k_finalize, gridFor(nKeys), WG, 0, s, ukeys.p, nKeys, isRep.p, repIdx.p, keepIdx.p,
+						   off.p, c->dKeys.p, c->dKeyOff.p, c->dRepKeys.p);
+	}
+	HIP_CHECK(hipMemcpyAsync(c->dKeyOff.p + nKeep, &nEnt, 8, hipMemcpyHostToDevice, s));
+	if (E)
+	{
+		ScopedK t(c->timer, "k_entries");
+		hipLaunchKernelGGL(k_entries, gridFor(E), WG, 0, s, evalue.p, E, inc.p, kstart.p, size.p, off.p, posBits,
+						   c->dEntries.p);
+	}
+	c->nKeys = nKeep; c->nEntries = nEnt; c->nRep = nRep;
+
+	// probe table at load <= 0.5
+	u64 slots = 1024;
+	while (slots < 2 * (nKeep + nRep)) slots <<= 1;
+	c->tableSlots = slots;
+	c->dTable.alloc(slots);
+	HIP_CHECK(hipMemsetAsync(c->dTable.p, 0xFF, slots * sizeof(ulonglong2), s));
+	if (nKeep + nRep)
+	{
+		ScopedK t(c->timer, "k_table_insert");
+		hipLaunchKernelGGL(k_table_insert, gridFor(nKeep + nRep), WG, 0, s, c->dKeys.p, c->dKeyOff.p, nKeep,
+						   c->dRepKeys.p, nRep, c->dTable.p, slots - 1);
+	}
+	c->dIndexedBits.alloc((c->totalKmers + 31) / 32 + 1);
+	HIP_CHECK(hipMemsetAsync(c->dIndexedBits.p, 0, c->dIndexedBits.bytes(), s));
+	if (n)
+	{
+		ScopedK t(c->timer, "k_indexed_bits");
+		hipLaunchKernelGGL(k_indexed_bits, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+						   flags, c->dTable.p, slots - 1, c->dIndexedBits.p);
+	}
+	HIP_CHECK(hipStreamSynchronize(s));
+	st->selected_kmers = nKeep;
+	st->index_entries = nEnt;
+	st->repetitive_kmers = nRep;
+	c->indexBuilt = true;
+}
+
+struct BuildClock {
+	fg_ctx* c; hipEvent_t a, b;
+	BuildClock(fg_ctx* c_) : c(c_)
+	{
+		HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+		HIP_CHECK(hipEventRecord(a, c->stream));
+	}
+	double stop()
+	{
+		HIP_CHECK(hipEventRecord(b, c->stream));
+		HIP_CHECK(hipEventSynchronize(b));
+		float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+		return ms * 1e-3;
+	}
+	~BuildClock() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+};
+
+} // namespace
+
+void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, fg_index_stats* st)
+{
+	if (c->k > 17) throw FgError{FG_ERR_KMER_SIZE, "Can't use flat counter for k-mer size > 17"};
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 n = c->nReads;
+	memset(st, 0, sizeof(*st));
+	c->indexBuilt = false;
+	c->timer.evs.clear();
+	BuildClock clock(c);
+	Prim prim{c};
+
+	const u64 space = 1ULL << (2 * k);
+	DevBuf<u32> counts;
+	counts.alloc(space);
+	DevBuf<unsigned long long> scal;	// [0] distinct, [1] tandem candidates, [2] accepted, [3] cursor
+	scal.alloc(4);
+	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
+	{ ScopedK t(c->timer, "memset_counts"); HIP_CHECK(hipMemsetAsync(counts.p, 0, space * 4, s)); }
+	DevBuf<u32> freq, thr;
+	DevBuf<uint8_t> flags;
+	freq.alloc(c->totalKmers); flags.alloc(c->totalKmers); thr.alloc(n);
+	if (n)
+	{
+		{ ScopedK t(c->timer, "k_count");
+		  hipLaunchKernelGGL(k_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, k, counts.p, scal.p); }
+		{ ScopedK t(c->timer, "k_freq");
+		  hipLaunchKernelGGL(k_freq, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, counts.p, freq.p); }
+		{ ScopedK t(c->timer, "k_threshold");
+		  hipLaunchKernelGGL(k_threshold, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, selectRate, thr.p); }
+		{ ScopedK t(c->timer, "k_mark");
+		  hipLaunchKernelGGL(k_mark, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, thr.p, tandemFreq, flags.p, scal.p + 1); }
+	}
+	unsigned long long h[4];
+	HIP_CHECK(hipMemcpyAsync(h, scal.p, 32, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	st->total_kmers = h[0];
+	if (h[1] > 0)
+	{
+		u64 slots = 1024;
+		while (slots < 2 * h[1]) slots <<= 1;
+		DevBuf<u64> tkeys; DevBuf<u32> tcnt;
+		tkeys.alloc(slots); tcnt.alloc(slots);
+		HIP_CHECK(hipMemsetAsync(tkeys.p, 0xFF, slots * 8, s));
+		HIP_CHECK(hipMemsetAsync(tcnt.p, 0, slots * 4, s));
+		{ ScopedK t(c->timer, "k_tandem_insert");
+		  hipLaunchKernelGGL(k_tandem_insert, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+							 flags.p, tkeys.p, tcnt.p, slots - 1); }
+		{ ScopedK t(c->timer, "k_tandem_apply");
+		  hipLaunchKernelGGL(k_tandem_apply, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+							 flags.p, tkeys.p, tcnt.p, slots - 1, tandemFreq); }
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	if (n)
+	{
+		ScopedK t(c->timer, "k_accept");
+		hipLaunchKernelGGL(k_accept, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, minFreq, flags.p, scal.p + 2);
+	}
+	const u64 E = fetch(c, scal.p + 2);
+	freq.release();
+	DevBuf<u64> ecanon, evalue;
+	ecanon.alloc(E); evalue.alloc(E);
+	const int posBits = bitsFor((u64)c->maxLen);
+	if (n && E)
+	{
+		ScopedK t(c->timer, "k_emit");
+		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, flags.p,
+						   posBits, ecanon.p, evalue.p, scal.p + 3);
+	}
+	finishIndex(c, prim, ecanon, evalue, E, posBits, minFreq, repeatRate, counts.p, flags.p, st);
+	c->sampleRate = sampleRateInit;
+	st->sample_rate = sampleRateInit;
+	st->build_seconds = clock.stop();
+	c->timer.collect();
+}
+
+void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st)
+{
+	if (window < 1 || window > MAXW) throw FgError{FG_ERR_ARG, "wrong minimizer length"};
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 n = c->nReads;
+	memset(st, 0, sizeof(*st));
+	c->indexBuilt = false;
+	c->timer.evs.clear();
+	BuildClock clock(c);
+	Prim prim{c};
+
+	DevBuf<unsigned long long> scal;
+	scal.alloc(4);
+	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
+	DevBuf<uint8_t> flags;
+	flags.alloc(c->totalKmers);
+	{
+		DevBuf<u64> hashes;
+		hashes.alloc(window == 1 ? 1 : c->totalKmers);
+		if (n)
+		{
+			ScopedK t(c->timer, "k_minimizers");
+			hipLaunchKernelGGL(k_minimizers, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+							   window, hashes.p, flags.p, scal.p + 2);
+		}
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	const u64 E = fetch(c, scal.p + 2);
+	DevBuf<u64> ecanon, evalue;
+	ecanon.alloc(E); evalue.alloc(E);
+	const int posBits = bitsFor((u64)c->maxLen);
+	if (n && E)
+	{
+		ScopedK t(c->timer, "k_emit");
+		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, flags.p,
+						   posBits, ecanon.p, evalue.p, scal.p + 3);
+	}
+	finishIndex(c, prim, ecanon, evalue, E, posBits, minCoverage, repeatRate, nullptr, flags.p, st);
+	// vertex_index.cpp:480-482: _sampleRate = (float)totalLen / totalEntries
+	size_t totalLen = c->totalBases, totalEntries = c->nEntries;
+	float minimizerRate = (float)totalLen / totalEntries;
+	c->sampleRate = minimizerRate;
+	st->sample_rate = minimizerRate;
+	st->build_seconds = clock.stop();
+	c->timer.collect();
+}

@@ -1,0 +1,883 @@
+// Overlap stage on the device: seed collection, exact std::sort-order hit sort,
+// per-target chaining DP + backtrack + primary selection.  All kernels here are
+// hand-written for gfx950 (64-lane waves); no library primitive is used.
+//
+// Restates OverlapDetector::getSeqOverlaps (reference src/sequence/overlap.cpp:99-508)
+// phase by phase for a whole batch of query reads:
+//   k_probe / k_fill    seed collection                 overlap.cpp:176-196,
+//                       (+ index lookups)               vertex_index.h:139-246
+//   k_sort_hits         std::sort by (extId, curPos)    overlap.cpp:201-204
+//   k_group_*           equal-extId runs                overlap.cpp:216-234
+//   k_chain             prefilter, optional re-sort by extPos, chaining DP,
+//                       backtrack, overlapTest, primary selection
+//                                                       overlap.cpp:235-458, :29-69
+//   host shim           seqDivergence (libm), _maxDivergence gate, maxOverlaps
+//                       prefix rule, window statistics  overlap.cpp:417-423, :461-506
+//
+// Data layout in HBM: hits are a structure of arrays -- key = extId<<32 | curPos
+// (so the reference's (extId, curPos) comparator is one u64 compare) and
+// val = extPos -- dense per query in the reference's emission order (ascending
+// curPos, per k-mer ascending stored position).
+#include "fg_ctx.h"
+#include "../../include/introsort_emul.h"
+
+#include <algorithm>
+#include <cmath>
+
+#define WG 256
+#define FLAG_SELF (1ULL << 63)
+#define FLAG_FLIP (1ULL << 62)
+#define OFF_MASK ((1ULL << 38) - 1)
+
+namespace {
+
+// ---- block helpers ------------------------------------------------------------
+// exclusive scan of one u32 per thread over the 256-thread block; *total = block sum
+__device__ __forceinline__ u32 block_exscan(u32 v, u32* sh /* >= WG/64 + 1 */, u32* total)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	u32 inc = v;
+	for (int o = 1; o < 64; o <<= 1)
+	{
+		u32 t = __shfl_up(inc, o);
+		if (lane >= o) inc += t;
+	}
+	__syncthreads();
+	if (lane == 63) sh[w] = inc;
+	__syncthreads();
+	u32 base = 0, tot = 0;
+	for (int i = 0; i < WG / 64; ++i) { u32 s = sh[i]; if (i < w) base += s; tot += s; }
+	*total = tot;
+	return base + inc - v;
+}
+
+// single-block exclusive scan of n u64 (n+1 outputs), n = number of queries
+__global__ void k_exscan(const u64* __restrict__ in, u64* __restrict__ out, u32 n)
+{
+	__shared__ u64 sh[1024 / 64];
+	__shared__ u64 carry;
+	if (threadIdx.x == 0) carry = 0;
+	__syncthreads();
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	for (u32 base = 0; base < n; base += 1024)
+	{
+		const u32 i = base + threadIdx.x;
+		const u64 v = i < n ? in[i] : 0;
+		u64 inc = v;
+		for (int o = 1; o < 64; o <<= 1)
+		{
+			u64 t = __shfl_up(inc, o);
+			if (lane >= o) inc += t;
+		}
+		if (lane == 63) sh[w] = inc;
+		__syncthreads();
+		u64 b = carry;
+		for (int j = 0; j < w; ++j) b += sh[j];
+		if (i < n) out[i] = b + inc - v;
+		__syncthreads();
+		if (threadIdx.x == 1023) carry = b + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) out[n] = carry;
+}
+
+// ---- seed collection ---------------------------------------------------------------
+// per query k-mer: canonicalise, one probe; remember the slot value (+ flip and
+// self-hit flags) so that the fill pass needs no second probe.
+__global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ words,
+						const u64* __restrict__ wordOff, const i32* __restrict__ len,
+						const u64* __restrict__ kmerOff, const u64* __restrict__ qKmerOff, int k,
+						const ulonglong2* __restrict__ table, u64 tmask,
+						const u32* __restrict__ indexedBits, u64* __restrict__ probe,
+						u64* __restrict__ hitCnt, u64* __restrict__ filtCnt)
+{
+	__shared__ u32 shA[WG / 64], shB[WG / 64];
+	const u32 q = blockIdx.x;
+	const u32 rec = query[q];
+	const u32 r = rec >> 1;
+	const bool rc = rec & 1;
+	const i32 L = len[r];
+	const i32 nk = L - k;
+	const u64* w = words + wordOff[r];
+	u64* pr = probe + qKmerOff[q];
+	const u64 kbase = kmerOff[r];
+	u32 hits = 0, filt = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		const i32 qf = rc ? nk - p : p;	// forward-strand position of the same k-mer (L-k-p)
+		u64 a, b;
+		fg_kmer_pair(w, qf, k, a, b);
+		const u64 fw = rc ? b : a, rv = rc ? a : b;
+		const bool flip = rv < fw;
+		u64 v = fg_probe(table, tmask, flip ? rv : fw);
+		if (v != 0)
+		{
+			const u32 cnt = (u32)(v & FG_CNT_MASK);
+			if (cnt == FG_CNT_REPETITIVE) ++filt;
+			else
+			{
+				// forward position nk (= L-k) is never a forward k-mer position (kmer.h:193-198)
+				const u64 bit = kbase + (u64)qf;
+				const u32 self = qf < nk ? (indexedBits[bit >> 5] >> (bit & 31)) & 1u : 0u;
+				hits += cnt - self;
+				if (self) v |= FLAG_SELF;
+				if (flip) v |= FLAG_FLIP;
+			}
+		}
+		pr[p] = v;
+	}
+	// block sums
+	for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o); filt += __shfl_down(filt, o); }
+	if ((threadIdx.x & 63) == 0) { shA[threadIdx.x >> 6] = hits; shB[threadIdx.x >> 6] = filt; }
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		u64 h = 0, f = 0;
+		for (int i = 0; i < WG / 64; ++i) { h += shA[i]; f += shB[i]; }
+		hitCnt[q] = h; filtCnt[q] = f;
+	}
+}
+
+// expand every hit list in query order (overlap.cpp:176-196); a stored entry
+// (record, pos) is reported in the query k-mer's orientation (vertex_index.h:158-174)
+__global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len,
+					   const u64* __restrict__ qKmerOff, int k, u32 firstId,
+					   const u64* __restrict__ probe, const u64* __restrict__ entries,
+					   const u64* __restrict__ hitOff, const u64* __restrict__ filtOff,
+					   u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ filtPos)
+{
+	__shared__ u32 sh[WG / 64 + 1];
+	const u32 q = blockIdx.x;
+	const u32 rec = query[q];
+	const i32 nk = len[rec >> 1] - k;
+	const u64* pr = probe + qKmerOff[q];
+	u64 hbase = hitOff[q];
+	u64 fbase = filtOff[q];
+	for (i32 p0 = 0; p0 < nk; p0 += WG)
+	{
+		const i32 p = p0 + threadIdx.x;
+		u64 v = p < nk ? pr[p] : 0;
+		u32 cnt = (u32)(v & FG_CNT_MASK);
+		const bool rep = (cnt == FG_CNT_REPETITIVE);
+		if (rep) cnt = 0;
+		const u32 self = (v & FLAG_SELF) ? 1u : 0u;
+		u32 tot, ftot;
+		const u32 start = block_exscan(cnt - (cnt ? self : 0), sh, &tot);
+		const u32 fstart = block_exscan(rep ? 1u : 0u, sh, &ftot);
+		if (rep) filtPos[fbase + fstart] = p;
+		if (cnt)
+		{
+			const bool flip = v & FLAG_FLIP;
+			const u64 off = (v >> FG_CNT_BITS) & OFF_MASK;
+			u64 o = hbase + start;
+			for (u32 j = 0; j < cnt; ++j)
+			{
+				const u64 e = entries[off + j];
+				u32 srec = (u32)(e >> 32);
+				i32 spos = (i32)(u32)e;
+				if (flip) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
+				if (srec == rec && spos == p) continue;	// no trivial matches (overlap.cpp:188-190)
+				hitKey[o] = ((u64)(firstId + srec) << 32) | (u32)p;
+				hitVal[o] = (u32)spos;
+				++o;
+			}
+		}
+		hbase += tot;
+		fbase += ftot;
+	}
+}
+
+// ---- exact std::sort order, one wave per query --------------------------------------
+struct KV { u64 k; u32 v; };
+struct GlobalKV {
+	typedef KV T;
+	u64* K; u32* V;
+	__device__ KV load(int i) const { return KV{K[i], V[i]}; }
+	__device__ void store(int i, const KV& x) { K[i] = x.k; V[i] = x.v; }
+	__device__ bool less(const KV& a, const KV& b) const { return a.k < b.k; }
+};
+
+__device__ __forceinline__ int nth_set_bit(u64 m, int n)
+{
+	int pos = 0;
+	u32 c = __popc((u32)m);
+	if (n >= (int)c) { n -= c; pos += 32; m >>= 32; }
+	c = __popc((u32)m & 0xFFFFu); if (n >= (int)c) { n -= c; pos += 16; m >>= 16; }
+	c = __popc((u32)m & 0xFFu); if (n >= (int)c) { n -= c; pos += 8; m >>= 8; }
+	c = __popc((u32)m & 0xFu); if (n >= (int)c) { n -= c; pos += 4; m >>= 4; }
+	c = __popc((u32)m & 0x3u); if (n >= (int)c) { n -= c; pos += 2; m >>= 2; }
+	c = (u32)m & 1u; if (n >= (int)c) { pos += 1; }
+	return pos;
+}
+__device__ __forceinline__ int nth_set_bit_desc(u64 m, int n) { return 63 - nth_set_bit(__brevll(m), n); }
+
+__device__ __forceinline__ u64 shfl64(u64 v, int src)
+{
+	u32 lo = __shfl((u32)v, src), hi = __shfl((u32)(v >> 32), src);
+	return ((u64)hi << 32) | lo;
+}
+
+// memory written by some lanes of this wave is re-read by other lanes
+__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// median of (a, b, c) per std::__move_median_to_first; returns 0/1/2
+__device__ __forceinline__ int median3(u64 ka, u64 kb, u64 kc)
+{
+	if (ka < kb) { if (kb < kc) return 1; else if (ka < kc) return 2; else return 0; }
+	else if (ka < kc) return 0;
+	else if (kb < kc) return 2;
+	return 1;
+}
+
+// Hoare partition of the lanes' window (one element per lane, lanes [lo,hi) take
+// part) around pivot pk, with the closed-form of the unguarded two-pointer loop:
+// K = #swaps = max k with l_k < r_k (l_k = k-th lane from the left with key >= pk,
+// r_k = k-th from the right with key <= pk); cut = min(l_{K+1}, r_K), r_0 := hi.
+// Returns the new (key,val) of this lane and the cut lane.
+__device__ __forceinline__ int lane_partition(u64& key, u32& val, int lo, int hi, u64 pk)
+{
+	const int lane = threadIdx.x & 63;
+	const bool in = lane >= lo && lane < hi;
+	const bool ge = in && key >= pk;
+	const bool le = in && key <= pk;
+	const u64 mL = __ballot(ge), mR = __ballot(le);
+	const int cL = __popcll(mL), cR = __popcll(mR);
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+	const u64 above = (lane == 63) ? 0ULL : (~0ULL << (lane + 1));
+	const int rankL = __popcll(mL & below);
+	const int rankR = __popcll(mR & above);
+	const int partnerOfL = (ge && rankL < cR) ? nth_set_bit_desc(mR, rankL) : -1;
+	const bool swapL = ge && partnerOfL > lane;
+	const int K = __popcll(__ballot(swapL));
+	int src = lane;
+	if (swapL) src = partnerOfL;
+	else if (le && rankR < K) src = nth_set_bit(mL, rankR);
+	key = shfl64(key, src);
+	val = __shfl(val, src);
+	const int lK1 = (cL > K) ? nth_set_bit(mL, K) : 0x7fffffff;
+	const int rK = (K >= 1) ? nth_set_bit_desc(mR, K - 1) : hi;
+	return lK1 < rK ? lK1 : rK;
+}
+
+// whole segment (<= 64 elements) in registers: quicksort phase of introsort, then the
+// final insertion sort = stable placement by key
+__device__ void sort_small(u64* K, u32* V, int first, int n, int depth, int* stk /* LDS, >= 3*8 ints */)
+{
+	const int lane = threadIdx.x & 63;
+	u64 key = lane < n ? K[first + lane] : ~0ULL;
+	u32 val = lane < n ? V[first + lane] : 0u;
+	int sp = 0;
+	int a = 0, b = n, d = depth;
+	while (true)
+	{
+		while (b - a > 16)
+		{
+			if (d == 0)
+			{
+				// depth budget spent: heapsort this piece (sequential emulation, rare)
+				if (lane < n) { K[first + lane] = key; V[first + lane] = val; }
+				wave_mem_fence();
+				if (lane == 0) { GlobalKV acc{K, V}; fgsort::heap_sort_(acc, first + a, first + b); }
+				wave_mem_fence();
+				if (lane < n) { key = K[first + lane]; val = V[first + lane]; }
+				break;
+			}
+			--d;
+			const int mid = a + (b - a) / 2;
+			const u64 ka = shfl64(key, a + 1), kb = shfl64(key, mid), kc = shfl64(key, b - 1);
+			const int m3 = median3(ka, kb, kc);
+			const int pick = m3 == 0 ? a + 1 : (m3 == 1 ? mid : b - 1);
+			const u64 pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
+			const int src = lane == a ? pick : (lane == pick ? a : lane);
+			key = shfl64(key, src);
+			val = __shfl(val, src);
+			const int cut = lane_partition(key, val, a + 1, b, pk);
+			// both halves are independent; keep the smaller, stack the larger
+			if (cut - a < b - cut) { stk[sp++] = cut; stk[sp++] = b; stk[sp++] = d; b = cut; }
+			else { stk[sp++] = a; stk[sp++] = cut; stk[sp++] = d; a = cut; }
+		}
+		if (sp == 0) break;
+		d = stk[--sp]; b = stk[--sp]; a = stk[--sp];
+	}
+	// stable rank among the n lanes
+	int rank = 0;
+	for (int j = 0; j < n; ++j)
+	{
+		const u64 kj = shfl64(key, j);
+		rank += (kj < key) || (kj == key && j < lane);
+	}
+	if (lane < n) { K[first + rank] = key; V[first + rank] = val; }
+}
+
+// big segment: median-of-3 to first, then the two-pointer partition streamed in
+// chunks of up to 64 from both ends; the last <= 64 elements in registers
+__device__ int partition_big(u64* K, u32* V, int first, int last)
+{
+	const int lane = threadIdx.x & 63;
+	const int mid = first + (last - first) / 2;
+	const u64 ka = K[first + 1], kb = K[mid], kc = K[last - 1];
+	const int m3 = median3(ka, kb, kc);
+	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
+	const u64 pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
+	if (lane == 0)
+	{
+		const u64 k0 = K[first]; const u32 v0 = V[first]; const u32 vp = V[pick];
+		K[first] = pk; V[first] = vp;
+		K[pick] = k0; V[pick] = v0;
+	}
+	wave_mem_fence();
+	int f = first + 1, l = last;	// untouched window [f, l)
+	while (l - f > 64)
+	{
+		const int W = l - f;
+		const int wl = W / 2 < 64 ? W / 2 : 64;
+		const bool valid = lane < wl;
+		const int iL = f + lane, iR = l - 1 - lane;
+		u64 kL = 0, kR = 0; u32 vL = 0, vR = 0;
+		if (valid) { kL = K[iL]; vL = V[iL]; kR = K[iR]; vR = V[iR]; }
+		const bool geL = valid && kL >= pk;
+		const bool leR = valid && kR <= pk;
+		const u64 mL = __ballot(geL), mR = __ballot(leR);
+		const int cL = __popcll(mL), cR = __popcll(mR);
+		const int m = cL < cR ? cL : cR;
+		if (m > 0)
+		{
+			const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+			const int rankL = __popcll(mL & below), rankR = __popcll(mR & below);
+			if (geL && rankL < m)
+			{
+				const int dst = l - 1 - nth_set_bit(mR, rankL);
+				K[dst] = kL; V[dst] = vL;
+			}
+			if (leR && rankR < m)
+			{
+				const int dst = f + nth_set_bit(mL, rankR);
+				K[dst] = kR; V[dst] = vR;
+			}
+			const int lastL = nth_set_bit(mL, m - 1), lastR = nth_set_bit(mR, m - 1);
+			f = f + lastL + 1;
+			l = l - 1 - lastR;
+		}
+		else
+		{
+			if (cL == 0) f += wl;
+			if (cR == 0) l -= wl;
+		}
+	}
+	wave_mem_fence();
+	const int W = l - f;
+	u64 key = lane < W ? K[f + lane] : 0;
+	u32 val = lane < W ? V[f + lane] : 0;
+	const u64 key0 = key; const u32 val0 = val;
+	int cutLane = lane_partition(key, val, 0, W, pk);
+	if (lane < W && (key != key0 || val != val0)) { K[f + lane] = key; V[f + lane] = val; }
+	wave_mem_fence();
+	return f + cutLane;
+}
+
+__global__ void k_sort_hits(const u64* __restrict__ hitOff, u64* __restrict__ hitKey,
+							u32* __restrict__ hitVal, u32 nq)
+{
+	__shared__ int stack[WG / 64][3 * 40];
+	__shared__ int small[WG / 64][3 * 8];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const u32 q = blockIdx.x * (WG / 64) + wv;
+	if (q >= nq) return;
+	const u64 base = hitOff[q];
+	const u64 n64 = hitOff[q + 1] - base;
+	if (n64 < 2) return;
+	u64* K = hitKey + base;
+	u32* V = hitVal + base;
+	const int n = (int)n64;
+	int* stk = stack[wv];
+	int sp = 0;
+	int first = 0, last = n, depth = 2 * fgsort::floor_log2_(n);
+	while (true)
+	{
+		if (last - first <= 64)
+		{
+			if (last - first >= 2) sort_small(K, V, first, last - first, depth, small[wv]);
+		}
+		else if (depth == 0)
+		{
+			// depth budget spent on a big piece: sequential heapsort emulation (rare)
+			wave_mem_fence();
+			if (lane == 0) { GlobalKV acc{K, V}; fgsort::heap_sort_(acc, first, last); }
+			wave_mem_fence();
+		}
+		else
+		{
+			--depth;
+			const int cut = partition_big(K, V, first, last);
+			// process the smaller half next
+			if (cut - first < last - cut)
+			{
+				stk[sp++] = cut; stk[sp++] = last; stk[sp++] = depth;
+				last = cut;
+			}
+			else
+			{
+				stk[sp++] = first; stk[sp++] = cut; stk[sp++] = depth;
+				first = cut;
+			}
+			continue;
+		}
+		if (sp == 0) break;
+		depth = stk[--sp]; last = stk[--sp]; first = stk[--sp];
+	}
+}
+
+// ---- target groups ---------------------------------------------------------------------
+__global__ void k_group_count(const u64* __restrict__ hitOff, const u64* __restrict__ hitKey,
+							  u64* __restrict__ groupCnt)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 q = blockIdx.x;
+	const u64 b = hitOff[q], e = hitOff[q + 1];
+	u32 c = 0;
+	for (u64 i = b + threadIdx.x; i < e; i += WG)
+		c += (i == b) || ((hitKey[i] >> 32) != (hitKey[i - 1] >> 32));
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) { u64 t = 0; for (int i = 0; i < WG / 64; ++i) t += sh[i]; groupCnt[q] = t; }
+}
+
+__global__ void k_group_fill(const u64* __restrict__ hitOff, const u64* __restrict__ hitKey,
+							 const u64* __restrict__ groupOff, u64* __restrict__ groupStart,
+							 u32* __restrict__ groupQuery)
+{
+	__shared__ u32 sh[WG / 64 + 1];
+	const u32 q = blockIdx.x;
+	const u64 b = hitOff[q], e = hitOff[q + 1];
+	u64 gbase = groupOff[q];
+	for (u64 i0 = b; i0 < e; i0 += WG)
+	{
+		const u64 i = i0 + threadIdx.x;
+		const bool head = i < e && ((i == b) || ((hitKey[i] >> 32) != (hitKey[i - 1] >> 32)));
+		u32 tot;
+		const u32 pos = block_exscan(head ? 1u : 0u, sh, &tot);
+		if (head) { groupStart[gbase + pos] = i; groupQuery[gbase + pos] = q; }
+		gbase += tot;
+	}
+}
+
+// ---- chaining: one lane per target group ---------------------------------------------
+struct ChainParams {
+	int k, maxJump, minOverlap, maxOverhang;
+	int checkOverhang, forceLocal;
+	float minUnique;	// minKmerSruvivalRate * _minOverlap as a float (overlap.cpp:110, :235)
+	u32 firstId;
+};
+
+struct ExtAcc {	// re-sort of one group by extPos (overlap.cpp:269-275)
+	typedef KV T;
+	u64* K; u32* V;
+	__device__ KV load(int i) const { return KV{K[i], V[i]}; }
+	__device__ void store(int i, const KV& x) { K[i] = x.k; V[i] = x.v; }
+	__device__ bool less(const KV& a, const KV& b) const { return (i32)a.v < (i32)b.v; }
+};
+struct OrderAcc {	// chain starts by descending score (overlap.cpp:331-334)
+	typedef i32 T;
+	i32* ord; const i32* score;
+	__device__ i32 load(int i) const { return ord[i]; }
+	__device__ void store(int i, const i32& x) { ord[i] = x; }
+	__device__ bool less(const i32& a, const i32& b) const { return score[a] > score[b]; }
+};
+struct CandAcc {	// candidates by descending score (overlap.cpp:432-434); w = score
+	typedef int4 T;
+	int4* c;
+	__device__ int4 load(int i) const { return c[i]; }
+	__device__ void store(int i, const int4& x) { c[i] = x; }
+	__device__ bool less(const int4& a, const int4& b) const { return a.w > b.w; }
+};
+
+// overlap.cpp:29-69 with the float comparisons in their exact integer form
+// (operands < 2^24)
+__device__ __forceinline__ bool overlap_test(const ChainParams& P, u32 curId, u32 extId, i32 curLen,
+											 i32 extLen, i32 cb, i32 ce, i32 eb, i32 ee)
+{
+	const i32 curRange = ce - cb, extRange = ee - eb;
+	if (curRange < P.minOverlap || extRange < P.minOverlap) return false;
+	const float lengthDiff = (float)abs(curRange - extRange);
+	if (lengthDiff > 0.5f * (float)min(curRange, extRange)) return false;
+	if (curId == extId)
+	{
+		const i32 inter = min(ce, ee) - max(cb, eb);
+		if (inter > curRange / 2) return false;
+	}
+	if (curId == (extId ^ 1u))
+	{
+		const i32 inter = min(ce, extLen - eb) - max(cb, extLen - ee);
+		if (inter > curRange / 2) return false;
+	}
+	if (!P.forceLocal && P.checkOverhang)
+	{
+		const i32 ovh = max(min(cb, eb), min(curLen - ce, extLen - ee));
+		if (ovh > P.maxOverhang) return false;
+	}
+	return true;
+}
+
+__global__ void k_chain(ChainParams P, u64 nGroups, u64 nHits, const u64* __restrict__ groupStart,
+						const u32* __restrict__ groupQuery, const u32* __restrict__ query,
+						const i32* __restrict__ len, u64* __restrict__ hitKey, u32* __restrict__ hitVal,
+						i32* __restrict__ score, i32* __restrict__ back, i32* __restrict__ order,
+						int4* __restrict__ cand, const u64* __restrict__ filtOff,
+						const i32* __restrict__ filtPos, PrimRec* __restrict__ prim,
+						u32* __restrict__ primFlag, unsigned long long* __restrict__ counters)
+{
+	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
+	if (g >= nGroups) return;
+	const u64 g0 = groupStart[g];
+	primFlag[g] = 0;
+	const u32 q = groupQuery[g];
+	// hits are dense over the batch, so a group ends where the next one starts
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const i32 n = (i32)(gend - g0);
+	u64* K = hitKey + g0;
+	u32* V = hitVal + g0;
+	const int k = P.k;
+
+	// unique query positions (overlap.cpp:220-235); prevPos starts at 0
+	u32 unique = 0;
+	i32 prev = 0;
+	i32 minExt = 0x7fffffff, maxExt = (i32)0x80000000;
+	for (i32 i = 0; i < n; ++i)
+	{
+		const i32 c = (i32)(u32)K[i];
+		if (c != prev) { ++unique; prev = c; }
+		const i32 e = (i32)V[i];
+		minExt = min(minExt, e); maxExt = max(maxExt, e);
+	}
+	if ((float)unique < P.minUnique) return;
+
+	const u32 qrec = query[q];
+	const u32 curId = P.firstId + qrec;
+	const u32 extId = (u32)(K[0] >> 32);
+	const u32 extRec = extId - P.firstId;
+	const i32 curLen = len[qrec >> 1];
+	const i32 extLen = len[extRec >> 1];
+	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
+	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
+	if (P.checkOverhang && !P.forceLocal)
+	{
+		if (min(minCur, minExt) > P.maxOverhang) return;
+		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
+	}
+	atomicAdd(&counters[0], 1ULL);
+	atomicAdd(&counters[1], (unsigned long long)n);
+
+	int stack[fgsort::STACK_INTS];
+	const bool extSorted = extLen > curLen;
+	if (extSorted)
+	{
+		ExtAcc acc{K, V};
+		fgsort::sort(acc, 0, n, stack);
+	}
+
+	i32* sc = score + g0;
+	i32* bk = back + g0;
+	i32* od = order + g0;
+	int4* cd = cand + g0;
+	// chaining DP (overlap.cpp:266-323)
+	sc[0] = 0; bk[0] = -1;
+	for (i32 i = 1; i < n; ++i)
+	{
+		i32 maxScore = 0, maxId = 0;
+		const i32 curNext = (i32)(u32)K[i], extNext = (i32)V[i];
+		for (i32 j = i - 1; j >= 0; --j)
+		{
+			const i32 curPrev = (i32)(u32)K[j], extPrev = (i32)V[j];
+			const i32 dc = curNext - curPrev, de = extNext - extPrev;
+			if (0 < dc && dc < P.maxJump && 0 < de && de < P.maxJump)
+			{
+				const i32 matchScore = min(min(dc, de), k);
+				const i32 jumpDiv = abs(dc - de);
+				const i32 gapCost = jumpDiv > 100 ? 2 * jumpDiv : (jumpDiv >> 1);	// (int)(LG/SM_GAP * jumpDiv)
+				const i32 nextScore = sc[j] + matchScore - gapCost;
+				if (nextScore > maxScore)
+				{
+					maxScore = nextScore;
+					maxId = j;
+					if (jumpDiv == 0 && dc < k) break;
+				}
+			}
+			if (extSorted && de > P.maxJump) break;
+			if (!extSorted && dc > P.maxJump) break;
+		}
+		sc[i] = max(maxScore, k);
+		bk[i] = maxScore > k ? maxId : -1;
+	}
+
+	// chain starts in descending score order
+	for (i32 i = 0; i < n; ++i) od[i] = i;
+	{
+		OrderAcc acc{od, sc};
+		fgsort::sort(acc, 0, n, stack);
+	}
+	i32 ncand = 0;
+	for (i32 oi = 0; oi < n; ++oi)
+	{
+		const i32 start = od[oi];
+		if (bk[start] == -1) continue;
+		i32 firstM = 0, chainLength = 0, pos = start;
+		while (pos != -1)
+		{
+			firstM = pos;
+			++chainLength;
+			const i32 np = bk[pos];
+			bk[pos] = -1;
+			pos = np;
+		}
+		const i32 cb = (i32)(u32)K[firstM], eb = (i32)V[firstM];
+		const i32 ce = (i32)(u32)K[start] + k - 1, ee = (i32)V[start] + k - 1;
+		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
+		cd[ncand++] = make_int4(firstM, start, chainLength, sc[start] - sc[firstM] + k - 1);
+	}
+	if (ncand == 0) return;
+	// primary selection, onlyMaxExt (overlap.cpp:431-439): front() of the candidates
+	// sorted by descending score with std::sort
+	int4 best = cd[0];
+	if (ncand > 16)
+	{
+		CandAcc acc{cd};
+		fgsort::sort(acc, 0, ncand, stack);
+		best = cd[0];
+	}
+	else
+	{
+		// <= 16 elements: std::sort is a plain insertion sort = stable
+		for (i32 c = 1; c < ncand; ++c) if (cd[c].w > best.w) best = cd[c];
+	}
+	PrimRec r;
+	r.query = q; r.extId = extId;
+	r.curBegin = (i32)(u32)K[best.x]; r.extBegin = (i32)V[best.x];
+	r.curEnd = (i32)(u32)K[best.y] + k - 1; r.extEnd = (i32)V[best.y] + k - 1;
+	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
+	// repetitive query positions inside [curBegin, curEnd] (overlap.cpp:407-413)
+	{
+		const i32* fp = filtPos + filtOff[q];
+		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
+		i32 lo = 0, hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
+		const i32 a = lo;
+		lo = a; hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
+		r.filtered = lo - a;
+	}
+	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
+	prim[g] = r;
+	primFlag[g] = 1;
+}
+
+__global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
+							 u64* __restrict__ primCnt)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 q = blockIdx.x;
+	const u64 b = groupOff[q], e = groupOff[q + 1];
+	u32 c = 0;
+	for (u64 i = b + threadIdx.x; i < e; i += WG) c += primFlag[i];
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) { u64 t = 0; for (int i = 0; i < WG / 64; ++i) t += sh[i]; primCnt[q] = t; }
+}
+
+__global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
+							  const PrimRec* __restrict__ prim, const u64* __restrict__ primOff,
+							  PrimRec* __restrict__ out)
+{
+	__shared__ u32 sh[WG / 64 + 1];
+	const u32 q = blockIdx.x;
+	const u64 b = groupOff[q], e = groupOff[q + 1];
+	u64 obase = primOff[q];
+	for (u64 i0 = b; i0 < e; i0 += WG)
+	{
+		const u64 i = i0 + threadIdx.x;
+		const bool f = i < e && primFlag[i];
+		u32 tot;
+		const u32 pos = block_exscan(f ? 1u : 0u, sh, &tot);
+		if (f) out[obase + pos] = prim[i];
+		obase += tot;
+	}
+}
+
+template <class T>
+T fetchScalar(fg_ctx* c, const T* dptr)
+{
+	T v;
+	HIP_CHECK(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	return v;
+}
+
+} // namespace
+
+void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
+				uint8_t forceLocal, fg_overlap_batch* out)
+{
+	if (p->nucl_alignment) throw FgError{FG_ERR_UNSUPPORTED, "nucl_alignment (edlib divergence) is not built yet"};
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	c->timer.evs.clear();
+	hipEvent_t evA, evB;
+	HIP_CHECK(hipEventCreate(&evA)); HIP_CHECK(hipEventCreate(&evB));
+	HIP_CHECK(hipEventRecord(evA, s));
+
+	BatchOwner* own = new BatchOwner;
+	out->owner_ = own;
+	out->n_queries = nq;
+	own->queryOff.assign(nq + 1, 0);
+	own->statOff.assign(nq + 1, 0);
+
+	// query table
+	std::vector<u32> hq(nq);
+	std::vector<u64> hQKmerOff(nq + 1, 0);
+	u64 queryBp = 0;
+	for (u32 i = 0; i < nq; ++i)
+	{
+		hq[i] = queryIds[i] - c->firstId;
+		const i32 L = c->hLen[hq[i] >> 1];
+		hQKmerOff[i + 1] = hQKmerOff[i] + (u64)std::max(0, L - k);
+		queryBp += L;
+	}
+	const u64 totalQK = hQKmerOff[nq];
+	out->query_bp = queryBp;
+	out->query_kmers = totalQK;
+	if (nq == 0)
+	{
+		out->query_off = own->queryOff.data(); out->div_stats_off = own->statOff.data();
+		HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
+		return;
+	}
+	c->dQuery.reserve(nq); c->dQKmerOff.reserve(nq + 1);
+	c->dProbe.reserve(totalQK);
+	c->dHitOff.reserve(nq + 1); c->dFiltOff.reserve(nq + 1);
+	DevBuf<u64> cntA, cntB, groupCnt, groupOff, primCnt, primOff;
+	cntA.alloc(nq + 1); cntB.alloc(nq + 1); groupCnt.alloc(nq + 1); groupOff.alloc(nq + 1);
+	primCnt.alloc(nq + 1); primOff.alloc(nq + 1);
+	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, hq.data(), nq * 4ULL, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemcpyAsync(c->dQKmerOff.p, hQKmerOff.data(), (nq + 1) * 8ULL, hipMemcpyHostToDevice, s));
+
+	{ ScopedK t(c->timer, "k_probe");
+	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p,
+						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->dIndexedBits.p, c->dProbe.p,
+						 cntA.p, cntB.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, cntA.p, c->dHitOff.p, nq);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, cntB.p, c->dFiltOff.p, nq); }
+	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
+	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
+	out->seed_hits = nHits;
+	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
+	{ ScopedK t(c->timer, "k_fill");
+	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
+						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
+	{ ScopedK t(c->timer, "k_sort_hits");
+	  hipLaunchKernelGGL(k_sort_hits, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
+						 c->dHitVal.p, nq); }
+	{ ScopedK t(c->timer, "k_group_count");
+	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, groupCnt.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, groupCnt.p, groupOff.p, nq); }
+	const u64 nGroups = fetchScalar(c, groupOff.p + nq);
+	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
+	c->dScore.reserve(nHits + 1); c->dBack.reserve(nHits + 1); c->dOrder.reserve(nHits + 1);
+	c->dCand.reserve(nHits + 1);
+	DevBuf<PrimRec> prim, primOut;
+	DevBuf<u32> primFlag;
+	DevBuf<unsigned long long> counters;
+	prim.alloc(nGroups + 1); primFlag.alloc(nGroups + 1); counters.alloc(2);
+	HIP_CHECK(hipMemsetAsync(counters.p, 0, 16, s));
+	{ ScopedK t(c->timer, "k_group_fill");
+	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, groupOff.p, c->dGroupStart.p,
+						 c->dGroupQuery.p); }
+	ChainParams cp;
+	cp.k = k; cp.maxJump = p->max_jump; cp.minOverlap = p->min_overlap; cp.maxOverhang = p->max_overhang;
+	cp.checkOverhang = p->max_overhang > 0; cp.forceLocal = forceLocal ? 1 : 0;
+	{
+		const float minKmerSruvivalRate = 0.01;	// overlap.cpp:110
+		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
+	}
+	cp.firstId = c->firstId;
+	if (nGroups)
+	{
+		ScopedK t(c->timer, "k_chain");
+		hipLaunchKernelGGL(k_chain, (unsigned)((nGroups + WG - 1) / WG), WG, 0, s, cp, nGroups, nHits,
+						   c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p, c->dHitVal.p,
+						   c->dScore.p, c->dBack.p, c->dOrder.p, c->dCand.p, c->dFiltOff.p, c->dFiltPos.p,
+						   prim.p, primFlag.p, counters.p);
+	}
+	{ ScopedK t(c->timer, "k_prim_count");
+	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, groupOff.p, primFlag.p, primCnt.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, primCnt.p, primOff.p, nq); }
+	const u64 nPrim = fetchScalar(c, primOff.p + nq);
+	primOut.alloc(nPrim + 1);
+	{ ScopedK t(c->timer, "k_prim_gather");
+	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, groupOff.p, primFlag.p, prim.p, primOff.p, primOut.p); }
+	std::vector<PrimRec> hPrim(nPrim);
+	std::vector<u64> hPrimOff(nq + 1);
+	unsigned long long hCnt[2];
+	if (nPrim) HIP_CHECK(hipMemcpyAsync(hPrim.data(), primOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(hPrimOff.data(), primOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(hCnt, counters.p, 16, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipEventRecord(evB, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	out->dp_groups = hCnt[0];
+	out->dp_elements = hCnt[1];
+
+	// ---- host shim: floats with the host libm, the gate, prefix rule, window stats ----
+	const float sampleRate = c->sampleRate;
+	const float maxDiv = p->max_divergence;
+	const int STAT_WND = 10000;
+	own->recs.reserve(nPrim);
+	struct Wnd { i32 range; float div; };
+	std::vector<Wnd> wnd;
+	for (u32 qi = 0; qi < nq; ++qi)
+	{
+		own->queryOff[qi] = own->recs.size();
+		own->statOff[qi] = own->stats.size();
+		const i32 curLen = c->hLen[hq[qi] >> 1];
+		wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
+		size_t detected = 0;
+		for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
+		{
+			// groups are visited in ascending extId; the limit is tested at each group
+			// start against the overlaps accepted so far (overlap.cpp:218-219)
+			if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
+			const PrimRec& r = hPrim[j];
+			fg_overlap_rec o;
+			o.cur_id = queryIds[qi]; o.ext_id = r.extId;
+			o.cur_begin = r.curBegin; o.cur_end = r.curEnd; o.cur_len = curLen;
+			o.ext_begin = r.extBegin; o.ext_end = r.extEnd; o.ext_len = r.extLen;
+			o.score = r.score; o.chain_length = r.chainLength; o.filtered_positions = r.filtered;
+			o.edit_distance = r.editDistance; o.hpc_len_cur = r.hpcLenCur; o.hpc_len_ext = r.hpcLenExt;
+			// overlap.cpp:414-423
+			float normLen = std::max(o.cur_end - o.cur_begin, o.ext_end - o.ext_begin) - r.filtered;
+			float matchRate = (float)r.chainLength * sampleRate / normLen;
+			matchRate = std::min(matchRate, 1.0f);
+			o.seq_divergence = std::log(1 / matchRate) / k;
+			if (o.seq_divergence < maxDiv) { own->recs.push_back(o); ++detected; }
+			const size_t w = o.cur_begin / STAT_WND;
+			if (o.cur_end - o.cur_begin > wnd[w].range) { wnd[w].range = o.cur_end - o.cur_begin; wnd[w].div = o.seq_divergence; }
+		}
+		for (auto& w : wnd) if (w.range > 0) own->stats.push_back(w.div);
+	}
+	own->queryOff[nq] = own->recs.size();
+	own->statOff[nq] = own->stats.size();
+	out->n_recs = own->recs.size();
+	out->query_off = own->queryOff.data();
+	out->recs = own->recs.data();
+	out->n_div_stats = own->stats.size();
+	out->div_stats_off = own->statOff.data();
+	out->div_stats = own->stats.data();
+	float ms = 0;
+	HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
+	out->device_seconds = ms * 1e-3;
+	HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
+	c->timer.collect();
+}

@@ -1,0 +1,366 @@
+"""ctypes binding of libflyegpu.so + a host-side mirror of the reference's
+``VertexIndex`` / ``OverlapDetector`` / ``OverlapContainer`` interface.
+
+The reference is C++ and has no FFI; the binding a Flye
+maintainer would add is the C++ stub in INTEGRATION.md.  This Python mirror keeps
+the same names, argument meaning and error behaviour so that the parity tests read
+like calls into the reference:
+
+* ``VertexIndex.countKmers / buildIndexUnevenCoverage / buildIndexMinimizers /
+  clear / getSampleRate``  (reference src/sequence/vertex_index.h:213-218, :260)
+* ``OverlapDetector(...)`` ctor arguments (src/sequence/overlap.h:313-336)
+* ``OverlapContainer.quickSeqOverlaps / lazySeqOverlaps /
+  estimateOverlaperParameters / setDivergenceThreshold``
+  (src/sequence/overlap.cpp:518-574, :744-827)
+
+There is no CPU fallback: if the HIP library or a device is missing every entry
+point raises ``FlyeGpuError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflyegpu.so")
+
+REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4"),
+                      ("cur_end", "<i4"), ("cur_len", "<i4"), ("ext_begin", "<i4"),
+                      ("ext_end", "<i4"), ("ext_len", "<i4"), ("score", "<i4"),
+                      ("seq_divergence", "<f4"), ("chain_length", "<i4"),
+                      ("filtered_positions", "<i4"), ("edit_distance", "<i4"),
+                      ("hpc_len_cur", "<i4"), ("hpc_len_ext", "<i4")])
+
+ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
+               "fg_set_reads", "fg_build_index_solid", "fg_build_index_minimizers",
+               "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
+               "fg_kernel_times"]
+
+
+class FlyeGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libflyegpu error {code}: {msg}")
+        self.code = code
+
+
+class IndexStats(C.Structure):
+    _fields_ = [("total_kmers", C.c_uint64), ("selected_kmers", C.c_uint64),
+                ("index_entries", C.c_uint64), ("repetitive_kmers", C.c_uint64),
+                ("repetitive_frequency", C.c_uint64), ("mean_frequency", C.c_float),
+                ("sample_rate", C.c_float), ("build_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class DetectorParams(C.Structure):
+    _fields_ = [("max_jump", C.c_int32), ("min_overlap", C.c_int32),
+                ("max_overhang", C.c_int32), ("keep_alignment", C.c_uint8),
+                ("only_max_ext", C.c_uint8), ("nucl_alignment", C.c_uint8),
+                ("partition_bad_mappings", C.c_uint8), ("use_hpc", C.c_uint8),
+                ("pad_", C.c_uint8 * 3), ("max_divergence", C.c_float)]
+
+
+class OverlapBatch(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("n_recs", C.c_uint64), ("query_off", C.c_void_p),
+                ("recs", C.c_void_p), ("n_div_stats", C.c_uint64), ("div_stats_off", C.c_void_p),
+                ("div_stats", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
+                ("seed_hits", C.c_uint64), ("dp_groups", C.c_uint64), ("dp_elements", C.c_uint64),
+                ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("seconds", C.c_double), ("launches", C.c_uint64)]
+
+
+_LIB = None
+
+
+def load_library():
+    """Load libflyegpu.so.  Raises if it is missing -- the product never falls
+    back to a CPU path."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FlyeGpuError(-100, f"{LIB_PATH} not built: run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.fg_abi_version.restype = C.c_int
+        L.fg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        L.fg_destroy.argtypes = [C.c_void_p]
+        L.fg_strerror.restype = C.c_char_p
+        L.fg_strerror.argtypes = [C.c_int]
+        L.fg_last_error.restype = C.c_char_p
+        L.fg_last_error.argtypes = [C.c_void_p]
+        L.fg_set_reads.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fg_build_index_solid.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                           C.c_float, C.POINTER(IndexStats)]
+        L.fg_build_index_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                                C.POINTER(IndexStats)]
+        L.fg_clear_index.argtypes = [C.c_void_p]
+        L.fg_export_index.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.fg_overlaps.argtypes = [C.c_void_p, C.POINTER(DetectorParams), C.c_void_p, C.c_uint32,
+                                  C.c_int32, C.c_uint8, C.POINTER(OverlapBatch)]
+        L.fg_release_batch.argtypes = [C.POINTER(OverlapBatch)]
+        L.fg_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+class IndexExport:
+    def __init__(self, keys, key_off, entries, repetitive):
+        self.keys, self.key_off, self.entries, self.repetitive = keys, key_off, entries, repetitive
+
+
+class OverlapResult:
+    """Flat result of one batched ``getSeqOverlaps`` call."""
+
+    def __init__(self, query_ids, query_off, recs, stat_off, stats, batch):
+        self.query_ids, self.query_off, self.recs = query_ids, query_off, recs
+        self.stat_off, self.stats = stat_off, stats
+        self.query_bp, self.query_kmers = batch.query_bp, batch.query_kmers
+        self.seed_hits, self.dp_groups, self.dp_elements = batch.seed_hits, batch.dp_groups, batch.dp_elements
+        self.device_seconds = batch.device_seconds
+
+    def of(self, i):
+        return self.recs[int(self.query_off[i]):int(self.query_off[i + 1])]
+
+    def lines(self):
+        r = self.recs
+        bits = r["seq_divergence"].view(np.uint32)
+        return [f"{r['cur_id'][i]} {r['cur_begin'][i]} {r['cur_end'][i]} {r['cur_len'][i]} "
+                f"{r['ext_id'][i]} {r['ext_begin'][i]} {r['ext_end'][i]} {r['ext_len'][i]} "
+                f"{r['score'][i]} {bits[i]:08x}" for i in range(len(r))]
+
+
+class Context:
+    """One fg_ctx: a SequenceContainer's reads resident in HBM on one GPU."""
+
+    def __init__(self, kmer_size=17, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.fg_create(C.byref(h), device, kmer_size)
+        if rc != 0:
+            raise FlyeGpuError(rc, self.L.fg_strerror(rc).decode())
+        self.h = h
+        self.k = kmer_size
+        self.first_id = 0
+        self.n_reads = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FlyeGpuError(rc, f"{self.L.fg_strerror(rc).decode()}: {self.L.fg_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_reads(self, rs, first_seq_id=0):
+        self.rs = rs
+        self.first_id = first_seq_id
+        self.n_reads = rs.n
+        self._check(self.L.fg_set_reads(self.h, rs.n, rs.words.ctypes.data, rs.word_off.ctypes.data,
+                                        rs.length.ctypes.data, first_seq_id))
+
+    def kernel_times(self):
+        arr = (KernelTime * 64)()
+        n = self.L.fg_kernel_times(self.h, arr, 64)
+        return {arr[i].name.decode(): (arr[i].seconds, arr[i].launches) for i in range(min(n, 64))}
+
+
+class VertexIndex:
+    """Mirror of reference VertexIndex (src/sequence/vertex_index.h:66-300)."""
+
+    def __init__(self, ctx: Context, sample_rate: float):
+        self.ctx = ctx
+        self._sample_rate_init = float(sample_rate)
+        self._counted = False
+        self.stats = None
+
+    def countKmers(self):
+        """vertex_index.cpp:19-22.  Counting runs fused with the build on the device;
+        this only records that the caller asked for it (k > 17 raises like :504-507)."""
+        if self.ctx.k > 17:
+            raise FlyeGpuError(-6, "Can't use flat counter for k-mer size > 17")
+        self._counted = True
+
+    def buildIndexUnevenCoverage(self, globalMinFreq: int, selectRate: float, tandemFreq: int,
+                                 repeat_kmer_rate: float = 100.0):
+        if not self._counted:
+            raise FlyeGpuError(-4, "countKmers() must be called first")
+        st = IndexStats()
+        L = self.ctx.L
+        self.ctx._check(L.fg_build_index_solid(self.ctx.h, globalMinFreq, selectRate, tandemFreq,
+                                               repeat_kmer_rate, self._sample_rate_init, C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def buildIndexMinimizers(self, minCoverage: int, wndLen: int, repeat_kmer_rate: float = 100.0):
+        st = IndexStats()
+        L = self.ctx.L
+        self.ctx._check(L.fg_build_index_minimizers(self.ctx.h, minCoverage, wndLen, repeat_kmer_rate,
+                                                    C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def build(self, cfg: dict):
+        """Index build exactly as main_assemble.cpp:195-223 selects it."""
+        if cfg["use_minimizers"]:
+            return self.buildIndexMinimizers(1, int(cfg["minimizer_window"]), cfg["repeat_kmer_rate"])
+        self.countKmers()
+        return self.buildIndexUnevenCoverage(2, cfg["meta_read_top_kmer_rate"],
+                                             int(cfg["meta_read_filter_kmer_freq"]),
+                                             cfg["repeat_kmer_rate"])
+
+    def clear(self):
+        self.ctx._check(self.ctx.L.fg_clear_index(self.ctx.h))
+
+    def getSampleRate(self) -> float:
+        return self.stats["sample_rate"] if self.stats else self._sample_rate_init
+
+    def export(self) -> IndexExport:
+        L, h = self.ctx.L, self.ctx.h
+        nk, ne, nr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.ctx._check(L.fg_export_index(h, C.byref(nk), C.byref(ne), C.byref(nr), None, None, None, None))
+        keys = np.empty(nk.value, np.uint64)
+        off = np.empty(nk.value + 1, np.uint64)
+        ent = np.empty(ne.value, np.uint64)
+        rep = np.empty(nr.value, np.uint64)
+        self.ctx._check(L.fg_export_index(h, C.byref(nk), C.byref(ne), C.byref(nr), keys.ctypes.data,
+                                          off.ctypes.data, ent.ctypes.data, rep.ctypes.data))
+        return IndexExport(keys, off, ent, rep)
+
+
+class OverlapDetector:
+    """Ctor arguments of reference OverlapDetector (overlap.h:313-336)."""
+
+    def __init__(self, ctx: Context, vertexIndex: VertexIndex, maxJump: int, minOverlap: int,
+                 maxOverhang: int, keepAlignment: bool, onlyMaxExt: bool, maxDivergence: float,
+                 nuclAlignment: bool, partitionBadMappings: bool, useHpc: bool):
+        self.ctx, self.index = ctx, vertexIndex
+        self.p = DetectorParams(max_jump=maxJump, min_overlap=minOverlap, max_overhang=maxOverhang,
+                                keep_alignment=int(keepAlignment), only_max_ext=int(onlyMaxExt),
+                                nucl_alignment=int(nuclAlignment),
+                                partition_bad_mappings=int(partitionBadMappings), use_hpc=int(useHpc),
+                                max_divergence=float(maxDivergence))
+
+    @classmethod
+    def for_assemble(cls, ctx, index, cfg, min_overlap=1000):
+        """The detector main_assemble.cpp:229-238 builds."""
+        return cls(ctx, index, int(cfg["maximum_jump"]), min_overlap, int(cfg["maximum_overhang"]),
+                   False, True, 1.0, bool(cfg["reads_base_alignment"]), False,
+                   bool(cfg["hpc_scoring_on"]))
+
+    def getSeqOverlapsBatch(self, query_ids, forceLocal=False, maxOverlaps=0) -> OverlapResult:
+        q = np.ascontiguousarray(query_ids, dtype=np.uint32)
+        b = OverlapBatch()
+        L = self.ctx.L
+        self.ctx._check(L.fg_overlaps(self.ctx.h, C.byref(self.p), q.ctypes.data, len(q), maxOverlaps,
+                                      int(bool(forceLocal)), C.byref(b)))
+        try:
+            nq = len(q)
+            qo = np.ctypeslib.as_array(C.cast(b.query_off, C.POINTER(C.c_uint64)), (nq + 1,)).copy()
+            so = np.ctypeslib.as_array(C.cast(b.div_stats_off, C.POINTER(C.c_uint64)), (nq + 1,)).copy()
+            if b.n_recs:
+                raw = C.string_at(b.recs, b.n_recs * REC_DTYPE.itemsize)
+                recs = np.frombuffer(raw, dtype=REC_DTYPE).copy()
+            else:
+                recs = np.empty(0, REC_DTYPE)
+            if b.n_div_stats:
+                stats = np.ctypeslib.as_array(C.cast(b.div_stats, C.POINTER(C.c_float)), (b.n_div_stats,)).copy()
+            else:
+                stats = np.empty(0, np.float32)
+            return OverlapResult(q, qo, recs, so, stats, b)
+        finally:
+            L.fg_release_batch(C.byref(b))
+
+
+def complement(recs: np.ndarray) -> np.ndarray:
+    """OverlapRange::complement (overlap.h:118-147) on a record array."""
+    out = recs.copy()
+    out["cur_begin"] = recs["cur_len"] - recs["cur_end"] - 1
+    out["cur_end"] = recs["cur_len"] - recs["cur_begin"] - 1
+    out["ext_begin"] = recs["ext_len"] - recs["ext_end"] - 1
+    out["ext_end"] = recs["ext_len"] - recs["ext_begin"] - 1
+    out["cur_id"] = recs["cur_id"] ^ 1
+    out["ext_id"] = recs["ext_id"] ^ 1
+    return out
+
+
+class OverlapContainer:
+    """Mirror of reference OverlapContainer's query side (overlap.cpp:510-827).
+
+    Flye's worker threads ask for one read at a time; the device wants batches.
+    ``prefetch`` computes and caches a batch, ``lazySeqOverlaps`` serves single reads
+    from the cache (computing a batch of one on a miss)."""
+
+    def __init__(self, ovlpDetect: OverlapDetector, first_id=None, n_reads=None):
+        self.det = ovlpDetect
+        self.ctx = ovlpDetect.ctx
+        self._cache = {}
+        self._mean_true_ovlp_div = 0.0
+        self.divergence_stats = []
+
+    def quickSeqOverlaps(self, readId: int, maxOverlaps: int = 0, forceLocal: bool = False):
+        res = self.det.getSeqOverlapsBatch([readId], forceLocal, maxOverlaps)
+        self.divergence_stats.extend(res.stats.tolist())
+        return res.recs
+
+    def prefetch(self, readIds):
+        fwd = sorted({int(r) & ~1 for r in readIds if (int(r) & ~1) not in self._cache})
+        if not fwd:
+            return
+        res = self.det.getSeqOverlapsBatch(fwd, False, 0)
+        self.divergence_stats.extend(res.stats.tolist())
+        for i, rid in enumerate(fwd):
+            f = res.of(i).copy()
+            self._cache[rid] = (f, complement(f))
+
+    def lazySeqOverlaps(self, readId: int):
+        fid = int(readId) & ~1
+        if fid not in self._cache:
+            self.prefetch([fid])
+        f, r = self._cache[fid]
+        return f if (int(readId) & 1) == 0 else r
+
+    def indexSize(self):
+        return sum(len(f) for f, _ in self._cache.values())
+
+    def estimateOverlaperParameters(self, libc_rand=None):
+        """overlap.cpp:744-817: median over 1000 rand()-picked records of the divergence of
+        each record's longest overlap.  ``libc_rand`` defaults to glibc's rand() so the
+        draw sequence is the reference's."""
+        if libc_rand is None:
+            libc = C.CDLL(None)
+            libc.rand.restype = C.c_int
+            libc_rand = libc.rand
+        n_records = 2 * self.ctx.n_reads
+        picks = [self.ctx.first_id + (libc_rand() % n_records) for _ in range(1000)]
+        res = self.det.getSeqOverlapsBatch(picks, False, 0)
+        divs = []
+        for i in range(len(picks)):
+            o = res.of(i)
+            if len(o):
+                rng = o["cur_end"] - o["cur_begin"]
+                divs.append(o["seq_divergence"][int(np.argmax(rng))])  # first maximum, strict >
+        if divs:
+            v = sorted(divs)
+            self._mean_true_ovlp_div = float(np.float32(v[len(v) // 2]))  # utils.h median()
+            self.divergence_stats = []
+        else:
+            self._mean_true_ovlp_div = 0.5
+        return self._mean_true_ovlp_div
+
+    def setDivergenceThreshold(self, threshold: float, isRelative: bool):
+        """overlap.cpp:820-827"""
+        base = np.float32(self._mean_true_ovlp_div) if isRelative else np.float32(0.0)
+        self.det.p.max_divergence = float(base + np.float32(threshold))
+        return self.det.p.max_divergence
