@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gbp of reads overlapped per second (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the overlap stage (seed collection -> sort -> chaining ->
+OverlapRange records on the host) over this rank's shard of the query reads, with
+the 2-bit reads and the k-mer index already resident in HBM.  Workload at N = 1:
+BASELINE.json configs[1], "E.coli PB 50x" (synthetic, SURVEY.md §8d generator:
+4.64 Mb genome with planted repeats, 50x PacBio-raw-like reads, asm_raw_reads.cfg
+parameters).  For N > 1 the genome grows with N (weak scaling): reads shard by
+sequence id (flye_amd/dist.py), every rank holds the whole index, no data-path
+collective (SURVEY.md §8e option A).
+
+The JSON line also carries
+  roofline     for the kernel with the largest device time in the timed region:
+               algorithmic bytes (DESIGN.md "Algorithmic bytes") / HIP-event time
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on
+               this host's cores on a bounded sample of the same queries, same index.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: float) -> float:
+    """Per-launch algorithmic bytes of each overlap-stage kernel (SURVEY.md §8d:
+    B = 16.25 + 44 m + 20 d B/bp, split by the kernel that owns each term)."""
+    per_bp = {
+        "k_probe": 0.25 + 16.0,                 # 2-bit read + one 16 B slot probe per k-mer
+        "k_fill": m * (8.0 + 12.0),             # index entry read + hit write
+        "k_sort_hits": m * 24.0,                # one read + one write of each 12 B hit
+        "k_chain": d * (12.0 + 8.0) + 44.0 * ovl_per_bp,  # hit read + score/backptr write + record
+    }
+    return per_bp.get(kernel, 0.0) * bp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scale", type=float, default=None, help="genome scale (default = --gpus)")
+    ap.add_argument("--cpu-sample-bp", type=float, default=25e6)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    import torch.distributed as td
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from flye_amd import config, dist, gpu, workloads
+
+    scale = args.scale if args.scale is not None else float(world)
+    t0 = time.time()
+    rs, min_ovlp, preset = workloads.ecoli_pb50(seed=12345, scale=scale)
+    cfg = config.preset(preset)
+    t_gen = time.time() - t0
+
+    ctx = gpu.Context(int(cfg["kmer_size"]), local)
+    t0 = time.time()
+    ctx.set_reads(rs)
+    t_upload = time.time() - t0
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    st = vi.build(cfg)
+    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
+    queries = dist.shard_queries(rs.n, rank, world)
+    my_bp = int(rs.length[(queries // 2).astype(np.int64)].sum())
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return det.getSeqOverlapsBatch(queries)
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    ktimes = {}
+    dev_s = 0.0
+    for _ in range(args.steps):
+        res = step()
+        dev_s += res.device_seconds
+        for name, (sec, n) in ctx.kernel_times().items():
+            a = ktimes.setdefault(name, [0.0, 0])
+            a[0] += sec
+            a[1] += n
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    bp = torch.tensor([my_bp], dtype=torch.float64, device="cuda")
+    if world > 1:
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        td.all_reduce(bp, op=td.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total_bp = float(bp.item())
+
+    if rank == 0:
+        value = total_bp * args.steps / elapsed / 1e9
+        m = res.seed_hits / max(1, res.query_bp)
+        d = res.dp_elements / max(1, res.query_bp)
+        ovl = len(res.recs) / max(1, res.query_bp)
+        # dominant kernel of the timed region (HIP events on the library stream)
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0])
+        dom_name, (dom_sec, dom_n) = dom
+        launches_per_step = max(1, dom_n // args.steps)
+        avg_launch_s = dom_sec / max(1, dom_n)
+        alg = algorithmic_bytes(dom_name, res.query_bp, m, d, ovl) / launches_per_step
+        achieved = alg / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(dom_name, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Gbp reads overlapped/sec", "value": round(value, 6), "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "E.coli PB 50x (synthetic, raw-read cfg): overlap stage, index resident",
+                       "genome_bp": int(4_640_000 * scale), "reads": rs.n, "read_bp": rs.total_bases,
+                       "queries_per_rank": int(len(queries)), "min_overlap": min_ovlp, "kmer": int(cfg["kmer_size"]),
+                       "sharding": f"reads by id over {world} rank(s), index replicated, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_launch_s * 1e3, 4)},
+            "work": {"seed_hits_per_bp": round(m, 4), "dp_elements_per_bp": round(d, 4),
+                     "overlaps": int(len(res.recs)), "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
+                     "kernel_ms_per_step": {k: round(v[0] / args.steps * 1e3, 3) for k, v in
+                                            sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
+                     "index_build_s": round(st["build_seconds"], 3), "read_gen_s": round(t_gen, 2),
+                     "upload_s": round(t_upload, 3), "index_entries": int(st["index_entries"])},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(rs, cfg, vi, queries, args.cpu_sample_bp)
+            # parity on the timed workload itself: the sample's records must match
+            line["cpu_baseline"]["sample_records_identical"] = bool(line["cpu_baseline"].pop("_same")(res))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
+def cpu_baseline(rs, cfg, vi, queries, sample_bp):
+    """The CPU oracle on this host's cores over a bounded sample of the same queries
+    against the same index (imported from the device, so the CPU does not spend
+    minutes rebuilding it).  Checker/baseline only -- never the measured product."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    o = O.Oracle(int(cfg["kmer_size"]), threads=cores)
+    o.set_reads(rs)
+    ex = vi.export()
+    o.import_index(O.IndexExport(ex.keys, ex.key_off, ex.entries, ex.repetitive), vi.getSampleRate())
+    lens = rs.length[(queries // 2).astype(np.int64)]
+    n = int(np.searchsorted(np.cumsum(lens), sample_bp)) + 1
+    n = max(1, min(n, len(queries)))
+    sample = queries[:n]
+    p = O.detector_params(cfg)
+    t0 = time.perf_counter()
+    ores = o.overlaps(p, sample, threads=cores)
+    dt = time.perf_counter() - t0
+
+    def same(gres):
+        end = int(gres.query_off[n])
+        g = gres.recs[:end]
+        return (len(g) == len(ores.recs) and
+                all(np.array_equal(g[f], ores.recs[f]) for f in
+                    ("cur_id", "ext_id", "cur_begin", "cur_end", "ext_begin", "ext_end", "score")) and
+                np.array_equal(g["seq_divergence"].view(np.uint32), ores.recs["seq_divergence"].view(np.uint32)))
+
+    return {"value": round(ores.query_bp / dt / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} query reads ({ores.query_bp} bp) of the same workload, same index, "
+                      f"{dt:.2f} s wall", "_same": same}
+
+
+if __name__ == "__main__":
+    main()

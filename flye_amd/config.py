@@ -61,6 +61,26 @@ def preset(name: str) -> dict:
 
 def params_string(name: str) -> str:
     """``key=value,...`` form accepted by the reference's ``Config::addParameters``
-    (``config.h:84-96``) -- used to drive oracle/_ref/ref_dumper without cfg files."""
+    (``config.h:84-96``) -- lets the test-side reference dumper run without cfg files."""
     return ",".join(f"{k}={v!r}" if isinstance(v, float) else f"{k}={v}"
                     for k, v in PRESETS[name].items())
+
+
+def min_overlap_from_reads(lengths, read_type="raw", meta=False) -> int:
+    """Minimum-overlap selection of the pipeline driver (reference
+    flye/config/configurator.py:51-59, :86-96; ranges flye/config/py_cfg.py:31-37):
+    N90 of the read lengths rounded to 1 kb, clamped to [1000, 5000].  The assemble
+    stage then drops reads with length <= max(min_read, min_overlap)
+    (src/assemble/main_assemble.cpp:183)."""
+    ls = sorted((int(x) for x in lengths), reverse=True)
+    total = sum(ls)
+    n90, acc = 0, 0
+    for l in ls:
+        acc += l
+        if acc > 0.90 * total:
+            n90 = l
+            break
+    lo, hi = (1000, 1000) if read_type == "subasm" else (1000, 5000)
+    if meta:
+        hi = min(hi, 3000)
+    return max(lo, min(hi, int(round(n90 / 1000)) * 1000))

@@ -188,6 +188,16 @@ int fg_overlaps(fg_ctx* c, const struct fg_detector_params* p, const uint32_t* q
 	});
 }
 
+int fg_debug_sort_pairs(fg_ctx* c, uint64_t* keys, uint32_t* vals, const uint64_t* seg_off, uint32_t n_seg)
+{
+	if (!c || !seg_off || (seg_off[n_seg] && (!keys || !vals))) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgDebugSortPairs(c, keys, vals, seg_off, n_seg);
+	});
+}
+
 void fg_release_batch(struct fg_overlap_batch* b)
 {
 	if (!b) return;

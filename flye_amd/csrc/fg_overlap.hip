@@ -716,6 +716,22 @@ T fetchScalar(fg_ctx* c, const T* dptr)
 
 } // namespace
 
+void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg)
+{
+	hipStream_t s = c->stream;
+	const u64 n = segOff[nSeg];
+	DevBuf<u64> dK, dOff; DevBuf<u32> dV;
+	dK.alloc(n + 1); dV.alloc(n + 1); dOff.alloc(nSeg + 1);
+	HIP_CHECK(hipMemcpyAsync(dK.p, keys, n * 8, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemcpyAsync(dV.p, vals, n * 4, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemcpyAsync(dOff.p, segOff, (nSeg + 1) * 8ULL, hipMemcpyHostToDevice, s));
+	if (nSeg)
+		hipLaunchKernelGGL(k_sort_hits, (nSeg + WG / 64 - 1) / (WG / 64), WG, 0, s, dOff.p, dK.p, dV.p, nSeg);
+	HIP_CHECK(hipMemcpyAsync(keys, dK.p, n * 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(vals, dV.p, n * 4, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+}
+
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out)
 {

@@ -156,7 +156,7 @@ void* fs_create(const fs_params* p)
 		else
 			L = ((int64_t)p->medianLen * interp(p->lenModel == 0 ? Q_S05 : Q_S08, rng)) >> 16;
 		L = std::max<int64_t>(p->minLen, std::min<int64_t>(p->maxLen, L));
-		if (!p->circular && L > G) L = G;
+		if (L > G) L = G;	// a template never wraps more than once
 		int64_t start = p->circular ? (int64_t)rng.below(G) : (int64_t)rng.below(G - L + 1);
 		bool rc = rng.below(2);
 		buf.clear();
@@ -216,7 +216,7 @@ void fs_copy(void* h, uint64_t* words, uint64_t* wordOff, int32_t* len,
 	if (strand) memcpy(strand, s->strand.data(), s->strand.size());
 }
 
-// FASTA writer so the reference dumper (oracle/_ref) can load the same reads
+// FASTA writer so the test-side reference dumper can load the same reads
 // through the reference's own parser.  Read i is named "r<i>".
 int fs_write_fasta(void* h, const char* path, int64_t firstRead, int64_t nReads)
 {

@@ -36,7 +36,7 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
                "fg_set_reads", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
-               "fg_kernel_times"]
+               "fg_kernel_times", "fg_debug_sort_pairs"]
 
 
 class FlyeGpuError(RuntimeError):
@@ -104,6 +104,7 @@ def load_library():
                                   C.c_int32, C.c_uint8, C.POINTER(OverlapBatch)]
         L.fg_release_batch.argtypes = [C.POINTER(OverlapBatch)]
         L.fg_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
+        L.fg_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -169,6 +170,18 @@ class Context:
         self.n_reads = rs.n
         self._check(self.L.fg_set_reads(self.h, rs.n, rs.words.ctypes.data, rs.word_off.ctypes.data,
                                         rs.length.ctypes.data, first_seq_id))
+
+    def debug_sort_pairs(self, keys, seg_off):
+        """Device hit-sort kernel on independent segments; returns (sorted keys, permutation)."""
+        k = np.ascontiguousarray(keys, np.uint64).copy()
+        off = np.ascontiguousarray(seg_off, np.uint64)
+        v = np.empty(len(k), np.uint32)
+        for i in range(len(off) - 1):
+            a, b = int(off[i]), int(off[i + 1])
+            v[a:b] = np.arange(b - a, dtype=np.uint32)
+        self._check(self.L.fg_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, off.ctypes.data,
+                                               len(off) - 1))
+        return k, v
 
     def kernel_times(self):
         arr = (KernelTime * 64)()

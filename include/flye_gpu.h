@@ -165,6 +165,12 @@ void fg_release_batch(struct fg_overlap_batch* b);
 struct fg_kernel_time { const char* name; double seconds; uint64_t launches; };
 int fg_kernel_times(fg_ctx* ctx, struct fg_kernel_time* out, int max_entries);
 
+/* Test hook: run the device hit-sort kernel (std::sort order by key, ties as GCC
+ * libstdc++ introsort leaves them) on n_seg independent segments of (key, val)
+ * pairs, in place in the caller's host arrays; seg_off has n_seg + 1 entries. */
+int fg_debug_sort_pairs(fg_ctx* ctx, uint64_t* keys, uint32_t* vals,
+                        const uint64_t* seg_off, uint32_t n_seg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,97 @@
+"""Generates tests/golden/*.  Run in the build container (needs /root/reference
+and oracle/_ref/ref_dumper, see oracle/Makefile):
+
+    python tests/golden/make_golden.py
+
+Each case = seeded simulator parameters (inputs are regenerated from the seed, not
+stored) + what the UNMODIFIED reference (Flye 2.8.1 compiled from /root/reference)
+produced on those reads: an index digest and the full OverlapRange list.  The
+reference's own tests hold no vectors for this path, so these are
+the golden vectors; nothing of the reference's source is stored here.
+"""
+import gzip
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+from flye_amd import config, synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+CFG_DIR = "/root/reference/flye/config/bin_cfg/"
+
+CASES = [
+    dict(name="raw_pb", preset="raw", sim=dict(seed=101, genome_len=60_000, coverage=30, kind="pb_raw"),
+         min_read_len=1000),
+    dict(name="raw_ont_rc", preset="raw",
+         sim=dict(seed=102, genome_len=60_000, coverage=25, kind="ont_raw", n_homopolymers=40, n_tandems=60),
+         min_read_len=1000, rc_queries=True, max_overlaps=30),
+    dict(name="raw_div", preset="raw",
+         sim=dict(seed=103, genome_len=50_000, coverage=35, kind="pb_raw", n_tandems=80, n_homopolymers=30,
+                  n_repeat_families=10),
+         min_read_len=1000, div_mode="assemble"),
+    dict(name="raw_local", preset="raw", sim=dict(seed=104, genome_len=40_000, coverage=30, kind="pb_raw"),
+         min_read_len=1000, force_local=True),
+    dict(name="hifi", preset="hifi", sim=dict(seed=105, genome_len=60_000, coverage=25, kind="hifi"),
+         min_read_len=1000),
+    dict(name="corrected_local", preset="corrected",
+         sim=dict(seed=106, genome_len=50_000, coverage=25, kind="hifi", n_homopolymers=40, n_tandems=40),
+         min_read_len=1000, force_local=True),
+    dict(name="hifi_rc_max", preset="hifi", sim=dict(seed=107, genome_len=50_000, coverage=25, kind="hifi03"),
+         min_read_len=1000, rc_queries=True, max_overlaps=20),
+]
+
+
+def index_digest(ix):
+    h = hashlib.sha256()
+    for a in (ix.keys, ix.key_off, ix.entries, ix.repetitive):
+        h.update(np.ascontiguousarray(a, np.uint64).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    assert O.have_ref(), "oracle/_ref/ref_dumper missing: make -C oracle ref"
+    only = set(sys.argv[1:])
+    meta_path = os.path.join(HERE, "cases.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    for case in CASES:
+        name = case["name"]
+        if only and name not in only:
+            continue
+        with tempfile.TemporaryDirectory() as tmp:
+            fa = os.path.join(tmp, "reads.fasta")
+            rs = synth.simulate(fasta_path=fa, **case["sim"]).filter_min_len(case["min_read_len"])
+            info = O.run_ref(fa, config=CFG_DIR + config.CFG_FILES[case["preset"]], threads=8,
+                             min_read_len=case["min_read_len"], max_overlaps=case.get("max_overlaps", 0),
+                             force_local=case.get("force_local", False),
+                             div_mode=case.get("div_mode", "none"),
+                             index_out=os.path.join(tmp, "index.txt"), ovlp_out=os.path.join(tmp, "ovlp.txt"),
+                             rc_queries=case.get("rc_queries", False))
+            hdr, ix = O.parse_ref_index(os.path.join(tmp, "index.txt"), rs)
+            lines = open(os.path.join(tmp, "ovlp.txt")).read()
+            first = lines.split("\n", 1)[0].split()
+            ovhdr = {first[i]: first[i + 1] for i in range(1, len(first), 2)}
+            with gzip.GzipFile(os.path.join(HERE, name + ".ovlp.gz"), "wb", mtime=0) as f:
+                f.write(lines.encode())
+            entry = dict(case)
+            entry.update(n_reads=rs.n, total_bases=rs.total_bases,
+                         reads_sha256=hashlib.sha256(rs.words.tobytes() + rs.length.tobytes()).hexdigest(),
+                         index=dict(sample_rate_bits=hdr["sampleRateBits"], repetitive_frequency=int(hdr["repFreq"]),
+                                    total_kmers=int(hdr["numKmers"]), selected_kmers=int(hdr["keys"]),
+                                    repetitive_kmers=int(hdr["rep"]), index_entries=int(len(ix.entries)),
+                                    sha256=index_digest(ix)),
+                         max_div_bits=ovhdr["maxDivBits"], mean_div_bits=ovhdr["meanDivBits"],
+                         n_overlaps=info["overlaps"])
+            meta[name] = entry
+            print(name, "reads", rs.n, "overlaps", info["overlaps"], "ref overlap_s", info["overlap_s"], flush=True)
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

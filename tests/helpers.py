@@ -1,0 +1,43 @@
+import gzip
+import hashlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_reads(case):
+    from flye_amd import synth
+    rs = synth.simulate(**case["sim"]).filter_min_len(case["min_read_len"])
+    sha = hashlib.sha256(rs.words.tobytes() + rs.length.tobytes()).hexdigest()
+    assert sha == case["reads_sha256"], "simulator no longer reproduces the golden inputs"
+    return rs
+
+
+def golden_lines(name):
+    with gzip.open(os.path.join(GOLDEN, name + ".ovlp.gz"), "rt") as f:
+        return [l.strip() for l in f if l.strip() and not l.startswith("#")]
+
+
+def index_digest(ix):
+    h = hashlib.sha256()
+    for a in (ix.keys, ix.key_off, ix.entries, ix.repetitive):
+        h.update(np.ascontiguousarray(a, np.uint64).tobytes())
+    return h.hexdigest()
+
+
+def bits_to_float(hexbits: str) -> float:
+    return float(np.array([int(hexbits, 16)], np.uint32).view(np.float32)[0])
+
+
+def case_queries(case, n_reads):
+    start = 1 if case.get("rc_queries") else 0
+    return np.arange(start, 2 * n_reads, 2, dtype=np.uint32)
+
+
+def check_index_stats(st, gold):
+    for f in ("total_kmers", "selected_kmers", "index_entries", "repetitive_kmers", "repetitive_frequency"):
+        assert int(st[f]) == int(gold[f]), (f, st[f], gold[f])
+    assert np.float32(st["sample_rate"]).view(np.uint32) == int(gold["sample_rate_bits"], 16)

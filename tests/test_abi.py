@@ -1,0 +1,58 @@
+"""The C-ABI shared library loads on a CPU-only box and exports every symbol that
+include/flye_gpu.h declares.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "flye_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fg_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(built):
+    from flye_amd import gpu
+    lib = gpu.load_library()
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/flye_gpu.h but not exported"
+    assert set(gpu.ABI_SYMBOLS) <= set(names)
+    assert lib.fg_abi_version() == 1
+
+
+def test_error_strings_and_argument_checks(built):
+    from flye_amd import gpu
+    lib = gpu.load_library()
+    assert lib.fg_strerror(0) == b"ok"
+    assert b"CPU" in lib.fg_strerror(-1)
+    h = C.c_void_p()
+    assert lib.fg_create(C.byref(h), 0, 33) == -6      # k > 32 never fits KmerRepr
+    assert lib.fg_create(None, 0, 17) == -3
+
+
+def test_no_cpu_fallback_without_device(built):
+    """Without a HIP device the product must fail loudly, not fall back."""
+    import torch
+    from flye_amd import gpu
+    if torch.cuda.is_available():
+        return
+    try:
+        gpu.Context(17, 0)
+    except gpu.FlyeGpuError as e:
+        assert e.code == -1
+    else:
+        raise AssertionError("Context() succeeded without a GPU")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "flye_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"liboracle", r"oracle/", r"fo_[a-z_]+\("):
+                    assert not re.search(pat, src), f"{f} reaches into the test oracle ({pat})"

@@ -1,0 +1,280 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the golden
+vectors of the compiled reference and against the CPU oracle on the same seeded
+inputs.  Bit-exact (integers and the float's bit pattern)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import (bits_to_float, case_queries, check_index_stats, golden_lines, golden_reads,
+                     index_digest)
+
+pytestmark = pytest.mark.gpu
+
+RAW_CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local"]
+
+
+def _gpu_setup(rs, cfg):
+    from flye_amd import gpu
+    ctx = gpu.Context(int(cfg["kmer_size"]), 0)
+    ctx.set_reads(rs)
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    st = vi.build(cfg)
+    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
+    return ctx, vi, st, det
+
+
+def _oracle_setup(rs, cfg):
+    from oracle import oracle as O
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(rs)
+    st = o.build_index(cfg)
+    return o, st
+
+
+def _same_index(a, b):
+    return (np.array_equal(a.keys, b.keys) and np.array_equal(a.key_off, b.key_off)
+            and np.array_equal(a.entries, b.entries) and np.array_equal(a.repetitive, b.repetitive))
+
+
+@pytest.mark.parametrize("name", RAW_CASES)
+def test_golden_reference_vectors(built, golden_cases, name):
+    from flye_amd import config
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    cfg = config.preset(case["preset"])
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    check_index_stats(st, case["index"])
+    assert index_digest(vi.export()) == case["index"]["sha256"]
+    det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
+                                  maxOverlaps=case.get("max_overlaps", 0))
+    assert res.lines() == golden_lines(name)
+    assert len(res.recs) == case["n_overlaps"]
+
+
+@pytest.mark.parametrize("seed,kind,opts", [
+    (1, "pb_raw", dict(mixed=True)),
+    (2, "ont_raw", dict(max_overlaps=7, hp=50, tr=80)),
+    (3, "pb_raw", dict(force_local=True, max_div=0.2)),
+    (4, "pb_raw", dict(first_id=1000, rep=12)),
+])
+def test_against_oracle_variants(built, seed, kind, opts):
+    from flye_amd import config, gpu, synth
+    from oracle import oracle as O
+    rs = synth.simulate(seed=seed, genome_len=50_000, coverage=30, kind=kind,
+                        n_homopolymers=opts.get("hp", 8), n_tandems=opts.get("tr", 8),
+                        n_repeat_families=opts.get("rep", 4)).filter_min_len(1000)
+    cfg = config.preset("raw")
+    first = opts.get("first_id", 0)
+    ctx = gpu.Context(17, 0)
+    ctx.set_reads(rs, first)
+    vi = gpu.VertexIndex(ctx, 1.0)
+    gst = vi.build(cfg)
+    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
+    det.p.max_divergence = opts.get("max_div", 1.0)
+    o = O.Oracle(17)
+    o.set_reads(rs, first)
+    ost = o.build_index(cfg)
+    assert _same_index(vi.export(), o.export_index())
+    for f in ("total_kmers", "selected_kmers", "index_entries", "repetitive_kmers", "repetitive_frequency"):
+        assert gst[f] == ost[f]
+    q = first + (np.arange(0, 2 * rs.n) if opts.get("mixed") else np.arange(0, 2 * rs.n, 2))
+    q = q.astype(np.uint32)
+    gres = det.getSeqOverlapsBatch(q, forceLocal=opts.get("force_local", False),
+                                   maxOverlaps=opts.get("max_overlaps", 0))
+    ores = o.overlaps(O.detector_params(cfg, max_divergence=opts.get("max_div", 1.0)), q,
+                      max_overlaps=opts.get("max_overlaps", 0), force_local=opts.get("force_local", False))
+    assert gres.lines() == ores.lines()
+    assert np.array_equal(gres.query_off, ores.query_off)
+    assert np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32))
+    for f in ("chain_length", "filtered_positions"):
+        assert np.array_equal(gres.recs[f], ores.recs[f])
+    assert (gres.query_kmers, gres.seed_hits, gres.dp_groups, gres.dp_elements) == \
+           (ores.query_kmers, ores.seed_hits, ores.dp_groups, ores.dp_elements)
+    # batch invariance: any sub-batch gives the same per-read lists
+    sub = q[5:40:3]
+    part = det.getSeqOverlapsBatch(sub, forceLocal=opts.get("force_local", False),
+                                   maxOverlaps=opts.get("max_overlaps", 0))
+    pos = {int(x): i for i, x in enumerate(q)}
+    for j, rid in enumerate(sub):
+        a, b = part.of(j), gres.of(pos[int(rid)])
+        assert a.tobytes() == b.tobytes()
+
+
+def _median3_killer(n):
+    k = n // 2
+    a = np.zeros(n, np.uint64)
+    for i in range(1, k + 1):
+        if i % 2 == 1:
+            a[i - 1] = i
+            a[i] = k + i
+        a[k + i - 1] = 2 * i
+    return a
+
+
+def test_device_sort_equals_std_sort(built):
+    """k_sort_hits on its own: tie-heavy, patterned and adversarial inputs must come
+    out in exactly the permutation std::sort produces (heapsort fallback included)."""
+    from flye_amd import gpu
+    from oracle import oracle as O
+    rng = np.random.default_rng(7)
+    segs = []
+    for n in list(range(0, 70)) + [100, 128, 129, 191, 192, 193, 255, 257, 1000, 4097, 20000, 70000]:
+        for hi in (2, 5, 50, 1 << 40):
+            segs.append(rng.integers(0, hi, size=n, dtype=np.uint64))
+    for n in (17, 64, 65, 1000, 5000):
+        segs += [np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64)[::-1].copy(),
+                 np.zeros(n, np.uint64), (np.arange(n) % 3).astype(np.uint64),
+                 (np.arange(n) // 7).astype(np.uint64)]
+    for n in (64, 130, 1000, 20000, 100000):
+        segs += [_median3_killer(n), _median3_killer(n) // 3]
+    off = np.zeros(len(segs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in segs])
+    keys = np.concatenate(segs)
+    ctx = gpu.Context(17, 0)
+    sk, perm = ctx.debug_sort_pairs(keys, off)
+    for i, s in enumerate(segs):
+        a, b = int(off[i]), int(off[i + 1])
+        want = O.std_sort_perm(s)
+        assert np.array_equal(perm[a:b], want), f"segment {i} (n={len(s)}) permutation differs from std::sort"
+        assert np.array_equal(sk[a:b], s[want])
+
+
+def test_container_mirror_and_divergence_threshold(built, golden_cases):
+    """OverlapContainer mirror: estimateOverlaperParameters draws the reference's rand()
+    sequence and lands on the reference's threshold bit for bit; lazySeqOverlaps of a
+    reverse-complement id is complement() of the forward list (overlap.cpp:528-574)."""
+    from flye_amd import config, gpu
+    case = golden_cases["raw_div"]
+    rs = golden_reads(case)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    oc = gpu.OverlapContainer(det)
+    libc = C.CDLL(None)
+    libc.srand(1)
+    libc.rand.restype = C.c_int
+    mean = oc.estimateOverlaperParameters(libc.rand)
+    assert np.float32(mean).view(np.uint32) == int(case["mean_div_bits"], 16)
+    thr = oc.setDivergenceThreshold(cfg["assemble_ovlp_divergence"], bool(cfg["assemble_divergence_relative"]))
+    assert np.float32(thr).view(np.uint32) == int(case["max_div_bits"], 16)
+    oc.prefetch([0, 2, 4, 7])
+    f = oc.lazySeqOverlaps(6)
+    r = oc.lazySeqOverlaps(7)
+    assert len(f) == len(r) and r.tobytes() == gpu.complement(f).tobytes()
+    one = oc.quickSeqOverlaps(6)
+    assert one.tobytes() == f.tobytes()
+
+
+def test_edge_cases(built):
+    from flye_amd import config, gpu, synth
+    cfg = config.preset("raw")
+    rs = synth.simulate(seed=5, genome_len=20_000, coverage=12, kind="pb_raw").filter_min_len(1000)
+    # add degenerate reads: shorter than k, exactly k, and an unrelated read with no hits
+    from flye_amd.synth import ReadSet
+    extra_len = np.array([5, 17, 18, 3000], np.int32)
+    rng = np.random.default_rng(3)
+    words = [rs.words]
+    offs = list(rs.word_off)
+    for L in extra_len:
+        nw = (int(L) + 31) // 32
+        words.append(rng.integers(0, 1 << 63, size=nw, dtype=np.uint64))
+        offs.append(offs[-1] + nw)
+    rs2 = ReadSet(np.concatenate(words), np.array(offs, np.uint64), np.concatenate([rs.length, extra_len]),
+                  np.zeros(rs.n + 4, np.int64), np.zeros(rs.n + 4, np.uint8), int(rs.total_bases + extra_len.sum()))
+    ctx, vi, st, det = _gpu_setup(rs2, cfg)
+    from oracle import oracle as O
+    o, ost = _oracle_setup(rs2, cfg)
+    assert _same_index(vi.export(), o.export_index())
+    q = np.arange(0, 2 * rs2.n, dtype=np.uint32)
+    gres = det.getSeqOverlapsBatch(q)
+    ores = o.overlaps(O.detector_params(cfg), q)
+    assert gres.lines() == ores.lines()
+    # empty batch
+    empty = det.getSeqOverlapsBatch(np.empty(0, np.uint32))
+    assert len(empty.recs) == 0 and len(empty.query_off) == 1
+    # unsupported flag combinations fail loudly
+    det.p.keep_alignment = 1
+    with pytest.raises(gpu.FlyeGpuError) as e:
+        det.getSeqOverlapsBatch(q[:2])
+    assert e.value.code == -7
+    det.p.keep_alignment = 0
+    with pytest.raises(gpu.FlyeGpuError):
+        det.getSeqOverlapsBatch(np.array([2 * rs2.n + 10], np.uint32))   # id outside the container
+    # call order
+    ctx2 = gpu.Context(17, 0)
+    ctx2.set_reads(rs)
+    det2 = gpu.OverlapDetector.for_assemble(ctx2, gpu.VertexIndex(ctx2, 1.0), cfg)
+    with pytest.raises(gpu.FlyeGpuError) as e:
+        det2.getSeqOverlapsBatch(q[:2])
+    assert e.value.code == -4
+
+
+def test_full_size_properties(built):
+    """BASELINE.json configs[1] at full size (E. coli PB 50x, ~230 Mbp): size-independent
+    properties + a sampled record-for-record comparison with the oracle."""
+    from flye_amd import config, gpu, workloads
+    from oracle import oracle as O
+    rs, min_ovlp, preset = workloads.ecoli_pb50()
+    cfg = config.preset(preset)
+    k = int(cfg["kmer_size"])
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    ex = vi.export()
+    # index invariants: keys ascending & unique, lists ascending, every entry decodes to its key
+    assert np.all(np.diff(ex.keys.astype(np.int64)) > 0)
+    cnt = np.diff(ex.key_off.astype(np.int64))
+    assert cnt.sum() == len(ex.entries) == st["index_entries"]
+    d = np.diff(ex.entries.astype(np.int64))
+    inner = np.ones(len(ex.entries) - 1, bool)
+    inner[(ex.key_off[1:-1].astype(np.int64) - 1)[cnt[:-1] > 0]] = False
+    assert np.all(d[inner] > 0)
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, len(ex.entries), size=1_000_000)
+    rec = (ex.entries[pick] >> np.uint64(32)).astype(np.int64)
+    pos = (ex.entries[pick] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    read = rec >> 1
+    L = rs.length[read].astype(np.int64)
+    q = np.where(rec & 1, L - pos - k, pos)           # forward position of the stored k-mer
+    w0 = rs.word_off[read].astype(np.int64) + (q >> 5)
+    sh = ((q & 31) * 2).astype(np.uint64)
+    lo = rs.words[w0] >> sh
+    hi = np.where(sh > 0, rs.words[np.minimum(w0 + 1, len(rs.words) - 1)] << ((np.uint64(64) - sh) % np.uint64(64)), 0)
+    mask = np.uint64((1 << (2 * k)) - 1)
+    x = (lo | hi.astype(np.uint64)) & mask
+    fw = np.zeros_like(x)
+    t = x.copy()
+    for _ in range(k):
+        fw = (fw << np.uint64(2)) | (t & np.uint64(3))
+        t >>= np.uint64(2)
+    rv = (~x) & mask
+    canon = np.minimum(fw, rv)
+    key_of_entry = ex.keys[np.searchsorted(ex.key_off, pick.astype(np.uint64), side="right") - 1]
+    assert np.array_equal(canon, key_of_entry)
+    assert np.array_equal((rv < fw), (rec & 1).astype(bool))    # stored in the canonical orientation
+    # the full all-vs-all pass, twice: deterministic
+    allq = np.arange(0, 2 * rs.n, 2, dtype=np.uint32)
+    r1 = det.getSeqOverlapsBatch(allq)
+    r2 = det.getSeqOverlapsBatch(allq)
+    assert r1.recs.tobytes() == r2.recs.tobytes() and len(r1.recs) > 100_000
+    rr = r1.recs
+    assert np.all(rr["cur_end"] - rr["cur_begin"] >= 1000) and np.all(rr["ext_end"] - rr["ext_begin"] >= 1000)
+    assert np.all(rr["cur_end"] < rr["cur_len"]) and np.all(rr["ext_end"] < rr["ext_len"])
+    assert np.all(rr["seq_divergence"] < 1.0)
+    # ascending extId inside each query list (reference emission order)
+    same_q = rr["cur_id"][1:] == rr["cur_id"][:-1]
+    assert np.all(rr["ext_id"][1:][same_q] > rr["ext_id"][:-1][same_q])
+    # sampled oracle comparison on the same (device-built, invariant-checked) index
+    o = O.Oracle(k)
+    o.set_reads(rs)
+    o.import_index(O.IndexExport(ex.keys, ex.key_off, ex.entries, ex.repetitive), vi.getSampleRate())
+    sample = np.sort(rng.choice(rs.n, size=300, replace=False))
+    sq = (2 * sample).astype(np.uint32)
+    ores = o.overlaps(O.detector_params(cfg), sq)
+    want = ores.lines()
+    got = []
+    for i in sample:
+        part = r1.of(int(i))
+        bits = part["seq_divergence"].view(np.uint32)
+        got += [f"{p['cur_id']} {p['cur_begin']} {p['cur_end']} {p['cur_len']} {p['ext_id']} {p['ext_begin']} "
+                f"{p['ext_end']} {p['ext_len']} {p['score']} {bits[j]:08x}" for j, p in enumerate(part)]
+    assert got == want

@@ -1,0 +1,27 @@
+"""The CPU oracle (oracle/flye_oracle.cpp) against the golden vectors produced by
+the compiled, unmodified reference (tests/golden/make_golden.py)."""
+import pytest
+
+from helpers import (bits_to_float, case_queries, check_index_stats, golden_lines, golden_reads,
+                     index_digest)
+
+CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_golden(built, golden_cases, name):
+    from flye_amd import config
+    from oracle import oracle as O
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    cfg = config.preset(case["preset"])
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(rs)
+    st = o.build_index(cfg)
+    check_index_stats(st, case["index"])
+    assert index_digest(o.export_index()) == case["index"]["sha256"]
+    p = O.detector_params(cfg, max_divergence=bits_to_float(case["max_div_bits"]))
+    res = o.overlaps(p, case_queries(case, rs.n), max_overlaps=case.get("max_overlaps", 0),
+                     force_local=case.get("force_local", False))
+    assert res.lines() == golden_lines(name)
+    assert len(res.recs) == case["n_overlaps"]
