@@ -90,8 +90,9 @@ def test_against_oracle_variants(built, seed, kind, opts):
     assert np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32))
     for f in ("chain_length", "filtered_positions"):
         assert np.array_equal(gres.recs[f], ores.recs[f])
-    assert (gres.query_kmers, gres.seed_hits, gres.dp_groups, gres.dp_elements) == \
-           (ores.query_kmers, ores.seed_hits, ores.dp_groups, ores.dp_elements)
+    assert (gres.query_kmers, gres.seed_hits) == (ores.query_kmers, ores.seed_hits)
+    if not opts.get("max_overlaps"):   # with a limit the reference stops visiting groups early
+        assert (gres.dp_groups, gres.dp_elements) == (ores.dp_groups, ores.dp_elements)
     # batch invariance: any sub-batch gives the same per-read lists
     sub = q[5:40:3]
     part = det.getSeqOverlapsBatch(sub, forceLocal=opts.get("force_local", False),
