@@ -19,7 +19,7 @@
 // val = extPos -- dense per query in the reference's emission order (ascending
 // curPos, per k-mer ascending stored position).
 #include "fg_ctx.h"
-#include "../../include/introsort_emul.h"
+#include "fg_wavesort.h"
 
 #include <algorithm>
 #include <cmath>
@@ -187,245 +187,18 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 	}
 }
 
-// ---- exact std::sort order, one wave per query --------------------------------------
-struct KV { u64 k; u32 v; };
-struct GlobalKV {
-	typedef KV T;
-	u64* K; u32* V;
-	__device__ KV load(int i) const { return KV{K[i], V[i]}; }
-	__device__ void store(int i, const KV& x) { K[i] = x.k; V[i] = x.v; }
-	__device__ bool less(const KV& a, const KV& b) const { return a.k < b.k; }
-};
-
-__device__ __forceinline__ int nth_set_bit(u64 m, int n)
-{
-	int pos = 0;
-	u32 c = __popc((u32)m);
-	if (n >= (int)c) { n -= c; pos += 32; m >>= 32; }
-	c = __popc((u32)m & 0xFFFFu); if (n >= (int)c) { n -= c; pos += 16; m >>= 16; }
-	c = __popc((u32)m & 0xFFu); if (n >= (int)c) { n -= c; pos += 8; m >>= 8; }
-	c = __popc((u32)m & 0xFu); if (n >= (int)c) { n -= c; pos += 4; m >>= 4; }
-	c = __popc((u32)m & 0x3u); if (n >= (int)c) { n -= c; pos += 2; m >>= 2; }
-	c = (u32)m & 1u; if (n >= (int)c) { pos += 1; }
-	return pos;
-}
-__device__ __forceinline__ int nth_set_bit_desc(u64 m, int n) { return 63 - nth_set_bit(__brevll(m), n); }
-
-__device__ __forceinline__ u64 shfl64(u64 v, int src)
-{
-	u32 lo = __shfl((u32)v, src), hi = __shfl((u32)(v >> 32), src);
-	return ((u64)hi << 32) | lo;
-}
-
-// memory written by some lanes of this wave is re-read by other lanes
-__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-
-// median of (a, b, c) per std::__move_median_to_first; returns 0/1/2
-__device__ __forceinline__ int median3(u64 ka, u64 kb, u64 kc)
-{
-	if (ka < kb) { if (kb < kc) return 1; else if (ka < kc) return 2; else return 0; }
-	else if (ka < kc) return 0;
-	else if (kb < kc) return 2;
-	return 1;
-}
-
-// Hoare partition of the lanes' window (one element per lane, lanes [lo,hi) take
-// part) around pivot pk, with the closed-form of the unguarded two-pointer loop:
-// K = #swaps = max k with l_k < r_k (l_k = k-th lane from the left with key >= pk,
-// r_k = k-th from the right with key <= pk); cut = min(l_{K+1}, r_K), r_0 := hi.
-// Returns the new (key,val) of this lane and the cut lane.
-__device__ __forceinline__ int lane_partition(u64& key, u32& val, int lo, int hi, u64 pk)
-{
-	const int lane = threadIdx.x & 63;
-	const bool in = lane >= lo && lane < hi;
-	const bool ge = in && key >= pk;
-	const bool le = in && key <= pk;
-	const u64 mL = __ballot(ge), mR = __ballot(le);
-	const int cL = __popcll(mL), cR = __popcll(mR);
-	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	const u64 above = (lane == 63) ? 0ULL : (~0ULL << (lane + 1));
-	const int rankL = __popcll(mL & below);
-	const int rankR = __popcll(mR & above);
-	const int partnerOfL = (ge && rankL < cR) ? nth_set_bit_desc(mR, rankL) : -1;
-	const bool swapL = ge && partnerOfL > lane;
-	const int K = __popcll(__ballot(swapL));
-	int src = lane;
-	if (swapL) src = partnerOfL;
-	else if (le && rankR < K) src = nth_set_bit(mL, rankR);
-	key = shfl64(key, src);
-	val = __shfl(val, src);
-	const int lK1 = (cL > K) ? nth_set_bit(mL, K) : 0x7fffffff;
-	const int rK = (K >= 1) ? nth_set_bit_desc(mR, K - 1) : hi;
-	return lK1 < rK ? lK1 : rK;
-}
-
-// whole segment (<= 64 elements) in registers: quicksort phase of introsort, then the
-// final insertion sort = stable placement by key
-__device__ void sort_small(u64* K, u32* V, int first, int n, int depth, int* stk /* LDS, >= 3*8 ints */)
-{
-	const int lane = threadIdx.x & 63;
-	u64 key = lane < n ? K[first + lane] : ~0ULL;
-	u32 val = lane < n ? V[first + lane] : 0u;
-	int sp = 0;
-	int a = 0, b = n, d = depth;
-	while (true)
-	{
-		while (b - a > 16)
-		{
-			if (d == 0)
-			{
-				// depth budget spent: heapsort this piece (sequential emulation, rare)
-				if (lane < n) { K[first + lane] = key; V[first + lane] = val; }
-				wave_mem_fence();
-				if (lane == 0) { GlobalKV acc{K, V}; fgsort::heap_sort_(acc, first + a, first + b); }
-				wave_mem_fence();
-				if (lane < n) { key = K[first + lane]; val = V[first + lane]; }
-				break;
-			}
-			--d;
-			const int mid = a + (b - a) / 2;
-			const u64 ka = shfl64(key, a + 1), kb = shfl64(key, mid), kc = shfl64(key, b - 1);
-			const int m3 = median3(ka, kb, kc);
-			const int pick = m3 == 0 ? a + 1 : (m3 == 1 ? mid : b - 1);
-			const u64 pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
-			const int src = lane == a ? pick : (lane == pick ? a : lane);
-			key = shfl64(key, src);
-			val = __shfl(val, src);
-			const int cut = lane_partition(key, val, a + 1, b, pk);
-			// both halves are independent; keep the smaller, stack the larger
-			if (cut - a < b - cut) { stk[sp++] = cut; stk[sp++] = b; stk[sp++] = d; b = cut; }
-			else { stk[sp++] = a; stk[sp++] = cut; stk[sp++] = d; a = cut; }
-		}
-		if (sp == 0) break;
-		d = stk[--sp]; b = stk[--sp]; a = stk[--sp];
-	}
-	// stable rank among the n lanes
-	int rank = 0;
-	for (int j = 0; j < n; ++j)
-	{
-		const u64 kj = shfl64(key, j);
-		rank += (kj < key) || (kj == key && j < lane);
-	}
-	if (lane < n) { K[first + rank] = key; V[first + rank] = val; }
-}
-
-// big segment: median-of-3 to first, then the two-pointer partition streamed in
-// chunks of up to 64 from both ends; the last <= 64 elements in registers
-__device__ int partition_big(u64* K, u32* V, int first, int last)
-{
-	const int lane = threadIdx.x & 63;
-	const int mid = first + (last - first) / 2;
-	const u64 ka = K[first + 1], kb = K[mid], kc = K[last - 1];
-	const int m3 = median3(ka, kb, kc);
-	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
-	const u64 pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
-	if (lane == 0)
-	{
-		const u64 k0 = K[first]; const u32 v0 = V[first]; const u32 vp = V[pick];
-		K[first] = pk; V[first] = vp;
-		K[pick] = k0; V[pick] = v0;
-	}
-	wave_mem_fence();
-	int f = first + 1, l = last;	// untouched window [f, l)
-	while (l - f > 64)
-	{
-		const int W = l - f;
-		const int wl = W / 2 < 64 ? W / 2 : 64;
-		const bool valid = lane < wl;
-		const int iL = f + lane, iR = l - 1 - lane;
-		u64 kL = 0, kR = 0; u32 vL = 0, vR = 0;
-		if (valid) { kL = K[iL]; vL = V[iL]; kR = K[iR]; vR = V[iR]; }
-		const bool geL = valid && kL >= pk;
-		const bool leR = valid && kR <= pk;
-		const u64 mL = __ballot(geL), mR = __ballot(leR);
-		const int cL = __popcll(mL), cR = __popcll(mR);
-		const int m = cL < cR ? cL : cR;
-		if (m > 0)
-		{
-			const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-			const int rankL = __popcll(mL & below), rankR = __popcll(mR & below);
-			if (geL && rankL < m)
-			{
-				const int dst = l - 1 - nth_set_bit(mR, rankL);
-				K[dst] = kL; V[dst] = vL;
-			}
-			if (leR && rankR < m)
-			{
-				const int dst = f + nth_set_bit(mL, rankR);
-				K[dst] = kR; V[dst] = vR;
-			}
-			const int lastL = nth_set_bit(mL, m - 1), lastR = nth_set_bit(mR, m - 1);
-			f = f + lastL + 1;
-			l = l - 1 - lastR;
-		}
-		else
-		{
-			if (cL == 0) f += wl;
-			if (cR == 0) l -= wl;
-		}
-	}
-	wave_mem_fence();
-	const int W = l - f;
-	u64 key = lane < W ? K[f + lane] : 0;
-	u32 val = lane < W ? V[f + lane] : 0;
-	const u64 key0 = key; const u32 val0 = val;
-	int cutLane = lane_partition(key, val, 0, W, pk);
-	if (lane < W && (key != key0 || val != val0)) { K[f + lane] = key; V[f + lane] = val; }
-	wave_mem_fence();
-	return f + cutLane;
-}
-
+// ---- exact std::sort order, one wave per query (fg_wavesort.h) ---------------------
 __global__ void k_sort_hits(const u64* __restrict__ hitOff, u64* __restrict__ hitKey,
 							u32* __restrict__ hitVal, u32 nq)
 {
 	__shared__ int stack[WG / 64][3 * 40];
 	__shared__ int small[WG / 64][3 * 8];
 	const int wv = threadIdx.x >> 6;
-	const int lane = threadIdx.x & 63;
 	const u32 q = blockIdx.x * (WG / 64) + wv;
 	if (q >= nq) return;
 	const u64 base = hitOff[q];
 	const u64 n64 = hitOff[q + 1] - base;
-	if (n64 < 2) return;
-	u64* K = hitKey + base;
-	u32* V = hitVal + base;
-	const int n = (int)n64;
-	int* stk = stack[wv];
-	int sp = 0;
-	int first = 0, last = n, depth = 2 * fgsort::floor_log2_(n);
-	while (true)
-	{
-		if (last - first <= 64)
-		{
-			if (last - first >= 2) sort_small(K, V, first, last - first, depth, small[wv]);
-		}
-		else if (depth == 0)
-		{
-			// depth budget spent on a big piece: sequential heapsort emulation (rare)
-			wave_mem_fence();
-			if (lane == 0) { GlobalKV acc{K, V}; fgsort::heap_sort_(acc, first, last); }
-			wave_mem_fence();
-		}
-		else
-		{
-			--depth;
-			const int cut = partition_big(K, V, first, last);
-			// process the smaller half next
-			if (cut - first < last - cut)
-			{
-				stk[sp++] = cut; stk[sp++] = last; stk[sp++] = depth;
-				last = cut;
-			}
-			else
-			{
-				stk[sp++] = first; stk[sp++] = cut; stk[sp++] = depth;
-				first = cut;
-			}
-			continue;
-		}
-		if (sp == 0) break;
-		depth = stk[--sp]; last = stk[--sp]; first = stk[--sp];
-	}
+	wsort::wave_sort<u64>(hitKey + base, hitVal + base, (int)n64, stack[wv], small[wv]);
 }
 
 // ---- target groups ---------------------------------------------------------------------
@@ -471,6 +244,7 @@ struct ChainParams {
 	u32 firstId;
 };
 
+struct KV { u64 k; u32 v; };
 struct ExtAcc {	// re-sort of one group by extPos (overlap.cpp:269-275)
 	typedef KV T;
 	u64* K; u32* V;
@@ -672,6 +446,235 @@ __global__ void k_chain(ChainParams P, u64 nGroups, u64 nHits, const u64* __rest
 	primFlag[g] = 1;
 }
 
+// ---- chaining: one wave per target group, group staged in LDS ---------------------------
+// Same arithmetic as k_chain (the sequential restatement above, kept for oversized
+// groups), but the look-back loop over j runs 64 candidates per step across the lanes:
+// the reference's "first strictly better j while scanning down, with two early exits"
+// becomes an exclusive prefix-max over the lanes (lane order = scan order), a ballot of
+// the exit conditions and a pick of the last improving lane before the first exit.
+__device__ __forceinline__ i32 wave_incl_max(i32 v)
+{
+	const int lane = threadIdx.x & 63;
+	for (int o = 1; o < 64; o <<= 1)
+	{
+		const i32 t = __shfl_up(v, o);
+		if (lane >= o) v = max(v, t);
+	}
+	return v;
+}
+
+struct GroupList { u32 n; };
+
+#define CHAIN_CAP 256
+#define CHAIN_WAVES 4
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(CHAIN_WAVES * 64)
+k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+			 const u32* __restrict__ query, const i32* __restrict__ len,
+			 u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ gScore,
+			 i32* __restrict__ gBack, u32* __restrict__ gAux /* 3 u32 per hit */,
+			 int4* __restrict__ cand, const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
+			 PrimRec* __restrict__ prim, u32* __restrict__ primFlag,
+			 unsigned long long* __restrict__ counters)
+{
+	__shared__ u32 sCur[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ u32 sExt[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ i32 sScore[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ i32 sBack[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ u32 sOKey[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ u32 sOVal[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ int stack[CHAIN_WAVES][3 * 40];
+	__shared__ int small[CHAIN_WAVES][3 * 8];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const u32 li = blockIdx.x * CHAIN_WAVES + wv;
+	if (li >= nList) return;
+	const u64 g = list[li];
+	const u64 g0 = groupStart[g];
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u32 q = groupQuery[g];
+	const u64* K = hitKey + g0;
+	const u32* V = hitVal + g0;
+	const int k = P.k;
+
+	u32 *cur, *ext, *okey, *oval; i32 *score, *back;
+	if (USE_LDS)
+	{
+		cur = sCur[wv]; ext = sExt[wv]; score = sScore[wv]; back = sBack[wv]; okey = sOKey[wv]; oval = sOVal[wv];
+	}
+	else
+	{
+		cur = gAux + 3 * g0; okey = cur + n; oval = okey + n;
+		ext = hitVal + g0; score = gScore + g0; back = gBack + g0;
+	}
+
+	// stage + unique query positions (overlap.cpp:220-235; prevPos starts at 0) + ext range
+	u32 uniq = 0;
+	i32 minExt = 0x7fffffff, maxExt = (i32)0x80000000;
+	for (i32 i = lane; i < n; i += 64)
+	{
+		const u32 c = (u32)K[i];
+		const u32 e = V[i];
+		cur[i] = c;
+		if (USE_LDS) ext[i] = e;
+		const u32 pc = i ? (u32)K[i - 1] : 0u;
+		uniq += (c != pc);
+		minExt = min(minExt, (i32)e); maxExt = max(maxExt, (i32)e);
+	}
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		uniq += __shfl_xor(uniq, o);
+		minExt = min(minExt, __shfl_xor(minExt, o));
+		maxExt = max(maxExt, __shfl_xor(maxExt, o));
+	}
+	if ((float)uniq < P.minUnique) return;
+	const u32 qrec = query[q];
+	const u32 curId = P.firstId + qrec;
+	const u32 extId = (u32)(K[0] >> 32);
+	const u32 extRec = extId - P.firstId;
+	const i32 curLen = len[qrec >> 1];
+	const i32 extLen = len[extRec >> 1];
+	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
+	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
+	if (P.checkOverhang && !P.forceLocal)
+	{
+		if (min(minCur, minExt) > P.maxOverhang) return;
+		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
+	}
+	if (lane == 0)
+	{
+		atomicAdd(&counters[0], 1ULL);
+		atomicAdd(&counters[1], (unsigned long long)n);
+	}
+	wsort::wave_mem_fence();
+
+	const bool extSorted = extLen > curLen;
+	if (extSorted) wsort::wave_sort<u32>(ext, cur, n, stack[wv], small[wv]);	// overlap.cpp:269-275
+
+	// chaining DP (overlap.cpp:266-323)
+	if (lane == 0) { score[0] = 0; back[0] = -1; }
+	wsort::wave_mem_fence();
+	const i32 maxJump = P.maxJump;
+	for (i32 i = 1; i < n; ++i)
+	{
+		const i32 cn = (i32)cur[i], en = (i32)ext[i];
+		i32 maxScore = 0, maxId = 0;
+		bool done = false;
+		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
+		{
+			const i32 j = jb - lane;
+			const bool valid = j >= 0;
+			i32 cp = 0, ep = 0, sj = 0;
+			if (valid) { cp = (i32)cur[j]; ep = (i32)ext[j]; sj = score[j]; }
+			const i32 dc = cn - cp, de = en - ep;
+			const bool inr = valid && dc > 0 && dc < maxJump && de > 0 && de < maxJump;
+			const i32 jd = abs(dc - de);
+			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : (i32)0x80000000;
+			const bool brkB = valid && (extSorted ? de > maxJump : dc > maxJump);
+			const bool brkA = inr && jd == 0 && dc < k;
+			const i32 inc = wave_incl_max(ns);
+			i32 exc = __shfl_up(inc, 1);
+			if (lane == 0) exc = (i32)0x80000000;
+			exc = max(exc, maxScore);
+			const bool upd = inr && ns > exc;
+			const u64 stopM = __ballot(brkB || (upd && brkA));
+			const u64 updM = __ballot(upd);
+			const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
+			const u64 um = updM & lim;
+			if (um)
+			{
+				const int lu = 63 - __clzll(um);
+				maxScore = __shfl(ns, lu);
+				maxId = jb - lu;
+			}
+			if (stopM) done = true;
+		}
+		if (lane == 0)
+		{
+			score[i] = max(maxScore, k);
+			back[i] = maxScore > k ? maxId : -1;
+		}
+		wsort::wave_mem_fence();
+	}
+
+	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
+	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
+	wsort::wave_mem_fence();
+	wsort::wave_sort<u32>(okey, oval, n, stack[wv], small[wv]);
+
+	if (lane != 0) return;
+	// backtrack, overlapTest, primary selection: short pointer chases, one lane
+	int4* cd = cand + g0;
+	i32 ncand = 0;
+	int4 best = make_int4(0, 0, 0, 0);
+	for (i32 oi = 0; oi < n; ++oi)
+	{
+		const i32 start = (i32)oval[oi];
+		if (back[start] == -1) continue;
+		i32 firstM = 0, chainLength = 0, pos = start;
+		while (pos != -1)
+		{
+			firstM = pos;
+			++chainLength;
+			const i32 np = back[pos];
+			back[pos] = -1;
+			pos = np;
+		}
+		const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
+		const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
+		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
+		const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
+		cd[ncand] = c4;
+		if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
+		++ncand;
+	}
+	if (ncand == 0) return;
+	if (ncand > 16)
+	{
+		int stk2[fgsort::STACK_INTS];
+		CandAcc acc{cd};
+		fgsort::sort(acc, 0, ncand, stk2);
+		best = cd[0];
+	}
+	PrimRec r;
+	r.query = q; r.extId = extId;
+	r.curBegin = (i32)cur[best.x]; r.extBegin = (i32)ext[best.x];
+	r.curEnd = (i32)cur[best.y] + k - 1; r.extEnd = (i32)ext[best.y] + k - 1;
+	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
+	{
+		const i32* fp = filtPos + filtOff[q];
+		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
+		i32 lo = 0, hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
+		const i32 a = lo;
+		hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
+		r.filtered = lo - a;
+	}
+	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
+	prim[g] = r;
+	primFlag[g] = 1;
+}
+
+// size classes for the chaining kernels; groups that cannot reach the minimum number
+// of distinct query positions are dropped here (unique <= size)
+__global__ void k_group_classify(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
+								 u32* __restrict__ listSmall, u32* __restrict__ listBig,
+								 u32* __restrict__ counts /* [0] small, [1] big */, u32* __restrict__ primFlag)
+{
+	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
+	if (g >= nGroups) return;
+	primFlag[g] = 0;
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const u64 n = gend - groupStart[g];
+	if (n < minSize) return;
+	if (n <= CHAIN_CAP) listSmall[atomicAdd(&counts[0], 1u)] = (u32)g;
+	else listBig[atomicAdd(&counts[1], 1u)] = (u32)g;
+}
+
 __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
 							 u64* __restrict__ primCnt)
 {
@@ -819,13 +822,39 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
 	}
 	cp.firstId = c->firstId;
+	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "batch too large: split the query list"};
 	if (nGroups)
 	{
-		ScopedK t(c->timer, "k_chain");
-		hipLaunchKernelGGL(k_chain, (unsigned)((nGroups + WG - 1) / WG), WG, 0, s, cp, nGroups, nHits,
-						   c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p, c->dHitVal.p,
-						   c->dScore.p, c->dBack.p, c->dOrder.p, c->dCand.p, c->dFiltOff.p, c->dFiltPos.p,
-						   prim.p, primFlag.p, counters.p);
+		// smallest group size that can still have >= minUnique distinct query positions
+		u32 minSize = 0;
+		while ((float)minSize < cp.minUnique) ++minSize;
+		DevBuf<u32> listSmall, listBig, listCnt;
+		listSmall.alloc(nGroups); listBig.alloc(nGroups); listCnt.alloc(2);
+		HIP_CHECK(hipMemsetAsync(listCnt.p, 0, 8, s));
+		{ ScopedK t(c->timer, "k_group_classify");
+		  hipLaunchKernelGGL(k_group_classify, (unsigned)((nGroups + WG - 1) / WG), WG, 0, s, nGroups, nHits,
+							 c->dGroupStart.p, minSize, listSmall.p, listBig.p, listCnt.p, primFlag.p); }
+		u32 hc[2];
+		HIP_CHECK(hipMemcpyAsync(hc, listCnt.p, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+		if (hc[0])
+		{
+			ScopedK t(c->timer, "k_chain_wave<lds>");
+			hipLaunchKernelGGL(k_chain_wave<true>, (hc[0] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
+							   cp, listSmall.p, hc[0], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
+							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, c->dScore.p, c->dBack.p, (u32*)nullptr,
+							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim.p, primFlag.p, counters.p);
+		}
+		if (hc[1])
+		{
+			c->dTmp32.reserve(3 * nHits + 3);
+			ScopedK t(c->timer, "k_chain_wave<global>");
+			hipLaunchKernelGGL(k_chain_wave<false>, (hc[1] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
+							   cp, listBig.p, hc[1], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
+							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, c->dScore.p, c->dBack.p, c->dTmp32.p,
+							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim.p, primFlag.p, counters.p);
+		}
+		HIP_CHECK(hipStreamSynchronize(s));
 	}
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, groupOff.p, primFlag.p, primCnt.p); }
