@@ -43,7 +43,10 @@ def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: fl
         "k_sort_hits": m * 24.0,                # one read + one write of each 12 B hit
         "k_chain": d * (12.0 + 8.0) + 44.0 * ovl_per_bp,  # hit read + score/backptr write + record
     }
-    return per_bp.get(kernel, 0.0) * bp
+    base = kernel.split("<")[0]
+    if base.startswith("k_chain"):
+        base = "k_chain"
+    return per_bp.get(base, 0.0) * bp
 
 
 def main():

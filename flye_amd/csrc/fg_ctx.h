@@ -51,6 +51,27 @@ struct DevBuf {
 	size_t bytes() const { return n * sizeof(T); }
 };
 
+// page-locked host staging buffer (grow-only)
+template <class T>
+struct PinnedBuf {
+	T* p = nullptr;
+	size_t n = 0;
+	PinnedBuf() {}
+	PinnedBuf(const PinnedBuf&) = delete;
+	PinnedBuf& operator=(const PinnedBuf&) = delete;
+	~PinnedBuf() { if (p) (void)hipHostFree(p); }
+	void reserve(size_t count)
+	{
+		if (count <= n) return;
+		if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+		count += count / 8;
+		hipError_t e = hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault);
+		if (e != hipSuccess)
+			throw FgError{FG_ERR_NOMEM, "hipHostMalloc of " + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e)};
+		n = count;
+	}
+};
+
 // --- per-kernel timing with HIP events on the library stream -------------------
 struct KernelTimer {
 	struct Ev { const char* name; hipEvent_t a, b; };
@@ -154,8 +175,11 @@ struct fg_ctx {
 	DevBuf<u64> dGroupStart;	// group boundaries (indices into hits)
 	DevBuf<u32> dGroupQuery;
 	DevBuf<u32> dTmp32;
-	DevBuf<u64> dTmp64;
-	DevBuf<u64> dCounters;
+	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
+	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListCnt;
+	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
+	PinnedBuf<char> hPrim;
+	PinnedBuf<u64> hOff;
 
 	~fg_ctx() { if (stream) (void)hipStreamDestroy(stream); }
 };

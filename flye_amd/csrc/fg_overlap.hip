@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
+#include <thread>
 
 #define WG 256
 #define FLAG_SELF (1ULL << 63)
@@ -236,29 +238,15 @@ __global__ void k_group_fill(const u64* __restrict__ hitOff, const u64* __restri
 	}
 }
 
-// ---- chaining: one lane per target group ---------------------------------------------
+// ---- chaining helpers -------------------------------------------------------------------
 struct ChainParams {
 	int k, maxJump, minOverlap, maxOverhang;
 	int checkOverhang, forceLocal;
 	float minUnique;	// minKmerSruvivalRate * _minOverlap as a float (overlap.cpp:110, :235)
 	u32 firstId;
+	int ablate;			// timing experiments only (FG_ABLATE env, results become wrong)
 };
 
-struct KV { u64 k; u32 v; };
-struct ExtAcc {	// re-sort of one group by extPos (overlap.cpp:269-275)
-	typedef KV T;
-	u64* K; u32* V;
-	__device__ KV load(int i) const { return KV{K[i], V[i]}; }
-	__device__ void store(int i, const KV& x) { K[i] = x.k; V[i] = x.v; }
-	__device__ bool less(const KV& a, const KV& b) const { return (i32)a.v < (i32)b.v; }
-};
-struct OrderAcc {	// chain starts by descending score (overlap.cpp:331-334)
-	typedef i32 T;
-	i32* ord; const i32* score;
-	__device__ i32 load(int i) const { return ord[i]; }
-	__device__ void store(int i, const i32& x) { ord[i] = x; }
-	__device__ bool less(const i32& a, const i32& b) const { return score[a] > score[b]; }
-};
 struct CandAcc {	// candidates by descending score (overlap.cpp:432-434); w = score
 	typedef int4 T;
 	int4* c;
@@ -294,176 +282,28 @@ __device__ __forceinline__ bool overlap_test(const ChainParams& P, u32 curId, u3
 	return true;
 }
 
-__global__ void k_chain(ChainParams P, u64 nGroups, u64 nHits, const u64* __restrict__ groupStart,
-						const u32* __restrict__ groupQuery, const u32* __restrict__ query,
-						const i32* __restrict__ len, u64* __restrict__ hitKey, u32* __restrict__ hitVal,
-						i32* __restrict__ score, i32* __restrict__ back, i32* __restrict__ order,
-						int4* __restrict__ cand, const u64* __restrict__ filtOff,
-						const i32* __restrict__ filtPos, PrimRec* __restrict__ prim,
-						u32* __restrict__ primFlag, unsigned long long* __restrict__ counters)
-{
-	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
-	if (g >= nGroups) return;
-	const u64 g0 = groupStart[g];
-	primFlag[g] = 0;
-	const u32 q = groupQuery[g];
-	// hits are dense over the batch, so a group ends where the next one starts
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
-	const i32 n = (i32)(gend - g0);
-	u64* K = hitKey + g0;
-	u32* V = hitVal + g0;
-	const int k = P.k;
-
-	// unique query positions (overlap.cpp:220-235); prevPos starts at 0
-	u32 unique = 0;
-	i32 prev = 0;
-	i32 minExt = 0x7fffffff, maxExt = (i32)0x80000000;
-	for (i32 i = 0; i < n; ++i)
-	{
-		const i32 c = (i32)(u32)K[i];
-		if (c != prev) { ++unique; prev = c; }
-		const i32 e = (i32)V[i];
-		minExt = min(minExt, e); maxExt = max(maxExt, e);
-	}
-	if ((float)unique < P.minUnique) return;
-
-	const u32 qrec = query[q];
-	const u32 curId = P.firstId + qrec;
-	const u32 extId = (u32)(K[0] >> 32);
-	const u32 extRec = extId - P.firstId;
-	const i32 curLen = len[qrec >> 1];
-	const i32 extLen = len[extRec >> 1];
-	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
-	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
-	if (P.checkOverhang && !P.forceLocal)
-	{
-		if (min(minCur, minExt) > P.maxOverhang) return;
-		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
-	}
-	atomicAdd(&counters[0], 1ULL);
-	atomicAdd(&counters[1], (unsigned long long)n);
-
-	int stack[fgsort::STACK_INTS];
-	const bool extSorted = extLen > curLen;
-	if (extSorted)
-	{
-		ExtAcc acc{K, V};
-		fgsort::sort(acc, 0, n, stack);
-	}
-
-	i32* sc = score + g0;
-	i32* bk = back + g0;
-	i32* od = order + g0;
-	int4* cd = cand + g0;
-	// chaining DP (overlap.cpp:266-323)
-	sc[0] = 0; bk[0] = -1;
-	for (i32 i = 1; i < n; ++i)
-	{
-		i32 maxScore = 0, maxId = 0;
-		const i32 curNext = (i32)(u32)K[i], extNext = (i32)V[i];
-		for (i32 j = i - 1; j >= 0; --j)
-		{
-			const i32 curPrev = (i32)(u32)K[j], extPrev = (i32)V[j];
-			const i32 dc = curNext - curPrev, de = extNext - extPrev;
-			if (0 < dc && dc < P.maxJump && 0 < de && de < P.maxJump)
-			{
-				const i32 matchScore = min(min(dc, de), k);
-				const i32 jumpDiv = abs(dc - de);
-				const i32 gapCost = jumpDiv > 100 ? 2 * jumpDiv : (jumpDiv >> 1);	// (int)(LG/SM_GAP * jumpDiv)
-				const i32 nextScore = sc[j] + matchScore - gapCost;
-				if (nextScore > maxScore)
-				{
-					maxScore = nextScore;
-					maxId = j;
-					if (jumpDiv == 0 && dc < k) break;
-				}
-			}
-			if (extSorted && de > P.maxJump) break;
-			if (!extSorted && dc > P.maxJump) break;
-		}
-		sc[i] = max(maxScore, k);
-		bk[i] = maxScore > k ? maxId : -1;
-	}
-
-	// chain starts in descending score order
-	for (i32 i = 0; i < n; ++i) od[i] = i;
-	{
-		OrderAcc acc{od, sc};
-		fgsort::sort(acc, 0, n, stack);
-	}
-	i32 ncand = 0;
-	for (i32 oi = 0; oi < n; ++oi)
-	{
-		const i32 start = od[oi];
-		if (bk[start] == -1) continue;
-		i32 firstM = 0, chainLength = 0, pos = start;
-		while (pos != -1)
-		{
-			firstM = pos;
-			++chainLength;
-			const i32 np = bk[pos];
-			bk[pos] = -1;
-			pos = np;
-		}
-		const i32 cb = (i32)(u32)K[firstM], eb = (i32)V[firstM];
-		const i32 ce = (i32)(u32)K[start] + k - 1, ee = (i32)V[start] + k - 1;
-		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
-		cd[ncand++] = make_int4(firstM, start, chainLength, sc[start] - sc[firstM] + k - 1);
-	}
-	if (ncand == 0) return;
-	// primary selection, onlyMaxExt (overlap.cpp:431-439): front() of the candidates
-	// sorted by descending score with std::sort
-	int4 best = cd[0];
-	if (ncand > 16)
-	{
-		CandAcc acc{cd};
-		fgsort::sort(acc, 0, ncand, stack);
-		best = cd[0];
-	}
-	else
-	{
-		// <= 16 elements: std::sort is a plain insertion sort = stable
-		for (i32 c = 1; c < ncand; ++c) if (cd[c].w > best.w) best = cd[c];
-	}
-	PrimRec r;
-	r.query = q; r.extId = extId;
-	r.curBegin = (i32)(u32)K[best.x]; r.extBegin = (i32)V[best.x];
-	r.curEnd = (i32)(u32)K[best.y] + k - 1; r.extEnd = (i32)V[best.y] + k - 1;
-	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
-	// repetitive query positions inside [curBegin, curEnd] (overlap.cpp:407-413)
-	{
-		const i32* fp = filtPos + filtOff[q];
-		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
-		i32 lo = 0, hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
-		const i32 a = lo;
-		lo = a; hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
-		r.filtered = lo - a;
-	}
-	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
-	prim[g] = r;
-	primFlag[g] = 1;
-}
-
 // ---- chaining: one wave per target group, group staged in LDS ---------------------------
-// Same arithmetic as k_chain (the sequential restatement above, kept for oversized
-// groups), but the look-back loop over j runs 64 candidates per step across the lanes:
+// The look-back loop over j (overlap.cpp:285-316) runs 64 candidates per step across the lanes:
 // the reference's "first strictly better j while scanning down, with two early exits"
 // becomes an exclusive prefix-max over the lanes (lane order = scan order), a ballot of
 // the exit conditions and a pick of the last improving lane before the first exit.
+#define I32_MIN ((i32)0x80000000)
+// lane L <- lane L-1, lane 0 <- fill (DPP wave_shr:1)
+__device__ __forceinline__ i32 wave_shr1(i32 v, i32 fill)
+{
+	return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix max over the 64 lanes with DPP row shifts + row broadcasts
 __device__ __forceinline__ i32 wave_incl_max(i32 v)
 {
-	const int lane = threadIdx.x & 63;
-	for (int o = 1; o < 64; o <<= 1)
-	{
-		const i32 t = __shfl_up(v, o);
-		if (lane >= o) v = max(v, t);
-	}
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x111, 0xf, 0xf, false));	// row_shr:1
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x112, 0xf, 0xf, false));	// row_shr:2
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x114, 0xf, 0xf, false));	// row_shr:4
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x118, 0xf, 0xf, false));	// row_shr:8
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x142, 0xa, 0xf, false));	// row_bcast:15
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x143, 0xc, 0xf, false));	// row_bcast:31
 	return v;
 }
-
-struct GroupList { u32 n; };
 
 #define CHAIN_CAP 256
 #define CHAIN_WAVES 4
@@ -476,8 +316,7 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 			 u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ gScore,
 			 i32* __restrict__ gBack, u32* __restrict__ gAux /* 3 u32 per hit */,
 			 int4* __restrict__ cand, const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
-			 PrimRec* __restrict__ prim, u32* __restrict__ primFlag,
-			 unsigned long long* __restrict__ counters)
+			 PrimRec* __restrict__ prim, u32* __restrict__ primFlag, u32* __restrict__ dpSize)
 {
 	__shared__ u32 sCur[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
 	__shared__ u32 sExt[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
@@ -544,41 +383,43 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		if (min(minCur, minExt) > P.maxOverhang) return;
 		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
 	}
-	if (lane == 0)
-	{
-		atomicAdd(&counters[0], 1ULL);
-		atomicAdd(&counters[1], (unsigned long long)n);
-	}
+	if (lane == 0) dpSize[g] = (u32)n;
 	wsort::wave_mem_fence();
 
 	const bool extSorted = extLen > curLen;
-	if (extSorted) wsort::wave_sort<u32>(ext, cur, n, stack[wv], small[wv]);	// overlap.cpp:269-275
+	if (extSorted && !(P.ablate & 4)) wsort::wave_sort<u32>(ext, cur, n, stack[wv], small[wv]);	// overlap.cpp:269-275
 
-	// chaining DP (overlap.cpp:266-323)
+	// chaining DP (overlap.cpp:266-323).  Lane L keeps element i-1-L of the scan in
+	// registers (a window sliding by one lane per i), so the usual look-back never
+	// touches memory; older elements come from LDS/global in further 64-wide steps.
 	if (lane == 0) { score[0] = 0; back[0] = -1; }
-	wsort::wave_mem_fence();
 	const i32 maxJump = P.maxJump;
-	for (i32 i = 1; i < n; ++i)
+	i32 wc = (i32)cur[0], we = (i32)ext[0], ws = 0;	// only lane 0 is meaningful for i = 1
+	i32 cnNext = n > 1 ? (i32)cur[1] : 0, enNext = n > 1 ? (i32)ext[1] : 0;
+	for (i32 i = 1; i < ((P.ablate & 1) ? 1 : n); ++i)
 	{
-		const i32 cn = (i32)cur[i], en = (i32)ext[i];
+		const i32 cn = cnNext, en = enNext;
+		if (i + 1 < n) { cnNext = (i32)cur[i + 1]; enNext = (i32)ext[i + 1]; }
 		i32 maxScore = 0, maxId = 0;
 		bool done = false;
 		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
 		{
 			const i32 j = jb - lane;
 			const bool valid = j >= 0;
-			i32 cp = 0, ep = 0, sj = 0;
-			if (valid) { cp = (i32)cur[j]; ep = (i32)ext[j]; sj = score[j]; }
+			i32 cp = wc, ep = we, sj = ws;
+			if (jb != i - 1)
+			{
+				cp = 0; ep = 0; sj = 0;
+				if (valid) { cp = (i32)cur[j]; ep = (i32)ext[j]; sj = score[j]; }
+			}
 			const i32 dc = cn - cp, de = en - ep;
 			const bool inr = valid && dc > 0 && dc < maxJump && de > 0 && de < maxJump;
 			const i32 jd = abs(dc - de);
-			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : (i32)0x80000000;
+			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : I32_MIN;
 			const bool brkB = valid && (extSorted ? de > maxJump : dc > maxJump);
 			const bool brkA = inr && jd == 0 && dc < k;
-			const i32 inc = wave_incl_max(ns);
-			i32 exc = __shfl_up(inc, 1);
-			if (lane == 0) exc = (i32)0x80000000;
-			exc = max(exc, maxScore);
+			// exclusive prefix max in scan order, seeded with the best of earlier steps
+			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
 			const bool upd = inr && ns > exc;
 			const u64 stopM = __ballot(brkB || (upd && brkA));
 			const u64 updM = __ballot(upd);
@@ -587,25 +428,27 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 			if (um)
 			{
 				const int lu = 63 - __clzll(um);
-				maxScore = __shfl(ns, lu);
+				maxScore = __builtin_amdgcn_readlane(ns, __builtin_amdgcn_readfirstlane(lu));
 				maxId = jb - lu;
 			}
 			if (stopM) done = true;
 		}
+		const i32 sNew = max(maxScore, k);
 		if (lane == 0)
 		{
-			score[i] = max(maxScore, k);
+			score[i] = sNew;
 			back[i] = maxScore > k ? maxId : -1;
 		}
-		wsort::wave_mem_fence();
+		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
 	}
+	wsort::wave_mem_fence();
 
 	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
 	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
 	wsort::wave_mem_fence();
-	wsort::wave_sort<u32>(okey, oval, n, stack[wv], small[wv]);
+	if (!(P.ablate & 2)) wsort::wave_sort<u32>(okey, oval, n, stack[wv], small[wv]);
 
-	if (lane != 0) return;
+	if (lane != 0 || (P.ablate & 8)) return;
 	// backtrack, overlapTest, primary selection: short pointer chases, one lane
 	int4* cd = cand + g0;
 	i32 ncand = 0;
@@ -634,9 +477,8 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	if (ncand == 0) return;
 	if (ncand > 16)
 	{
-		int stk2[fgsort::STACK_INTS];
 		CandAcc acc{cd};
-		fgsort::sort(acc, 0, ncand, stk2);
+		fgsort::sort(acc, 0, ncand, stack[wv]);	// 3*40 ints >= fgsort::STACK_INTS
 		best = cd[0];
 	}
 	PrimRec r;
@@ -663,30 +505,58 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 // of distinct query positions are dropped here (unique <= size)
 __global__ void k_group_classify(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
 								 u32* __restrict__ listSmall, u32* __restrict__ listBig,
-								 u32* __restrict__ counts /* [0] small, [1] big */, u32* __restrict__ primFlag)
+								 u32* __restrict__ counts /* [0] small, [1] big */, u32* __restrict__ primFlag,
+								 u32* __restrict__ dpSize)
 {
 	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
-	if (g >= nGroups) return;
-	primFlag[g] = 0;
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
-	const u64 n = gend - groupStart[g];
-	if (n < minSize) return;
-	if (n <= CHAIN_CAP) listSmall[atomicAdd(&counts[0], 1u)] = (u32)g;
-	else listBig[atomicAdd(&counts[1], 1u)] = (u32)g;
+	const int lane = threadIdx.x & 63;
+	u64 n = 0;
+	if (g < nGroups)
+	{
+		primFlag[g] = 0;
+		dpSize[g] = 0;
+		const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+		n = gend - groupStart[g];
+	}
+	const bool small = n >= minSize && n <= CHAIN_CAP;
+	const bool big = n > CHAIN_CAP && n >= minSize;
+	// one atomic per wave and list
+	const u64 mS = __ballot(small), mB = __ballot(big);
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+	u32 baseS = 0, baseB = 0;
+	if (lane == 0)
+	{
+		if (mS) baseS = atomicAdd(&counts[0], (u32)__popcll(mS));
+		if (mB) baseB = atomicAdd(&counts[1], (u32)__popcll(mB));
+	}
+	baseS = __shfl(baseS, 0); baseB = __shfl(baseB, 0);
+	if (small) listSmall[baseS + __popcll(mS & below)] = (u32)g;
+	if (big) listBig[baseB + __popcll(mB & below)] = (u32)g;
 }
 
 __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
-							 u64* __restrict__ primCnt)
+							 const u32* __restrict__ dpSize, u64* __restrict__ primCnt,
+							 u64* __restrict__ dpGroups, u64* __restrict__ dpElems)
 {
-	__shared__ u32 sh[WG / 64];
+	__shared__ u32 sh[3][WG / 64];
 	const u32 q = blockIdx.x;
 	const u64 b = groupOff[q], e = groupOff[q + 1];
-	u32 c = 0;
-	for (u64 i = b + threadIdx.x; i < e; i += WG) c += primFlag[i];
-	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+	u32 c = 0, dg = 0, de = 0;
+	for (u64 i = b + threadIdx.x; i < e; i += WG)
+	{
+		c += primFlag[i];
+		const u32 d = dpSize[i];
+		dg += d != 0; de += d;
+	}
+	for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); dg += __shfl_down(dg, o); de += __shfl_down(de, o); }
+	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = dg; sh[2][threadIdx.x >> 6] = de; }
 	__syncthreads();
-	if (threadIdx.x == 0) { u64 t = 0; for (int i = 0; i < WG / 64; ++i) t += sh[i]; primCnt[q] = t; }
+	if (threadIdx.x == 0)
+	{
+		u64 t0 = 0, t1 = 0, t2 = 0;
+		for (int i = 0; i < WG / 64; ++i) { t0 += sh[0][i]; t1 += sh[1][i]; t2 += sh[2][i]; }
+		primCnt[q] = t0; dpGroups[q] = t1; dpElems[q] = t2;
+	}
 }
 
 __global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
@@ -775,19 +645,19 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	c->dQuery.reserve(nq); c->dQKmerOff.reserve(nq + 1);
 	c->dProbe.reserve(totalQK);
 	c->dHitOff.reserve(nq + 1); c->dFiltOff.reserve(nq + 1);
-	DevBuf<u64> cntA, cntB, groupCnt, groupOff, primCnt, primOff;
-	cntA.alloc(nq + 1); cntB.alloc(nq + 1); groupCnt.alloc(nq + 1); groupOff.alloc(nq + 1);
-	primCnt.alloc(nq + 1); primOff.alloc(nq + 1);
+	c->dCntA.reserve(nq + 1); c->dCntB.reserve(nq + 1); c->dGroupCnt.reserve(nq + 1); c->dGroupOff.reserve(nq + 1);
+	c->dPrimCnt.reserve(nq + 1); c->dPrimOff.reserve(nq + 1); c->dDpGroups.reserve(nq + 1); c->dDpElems.reserve(nq + 1);
+	c->dListCnt.reserve(2);
 	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, hq.data(), nq * 4ULL, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(c->dQKmerOff.p, hQKmerOff.data(), (nq + 1) * 8ULL, hipMemcpyHostToDevice, s));
 
 	{ ScopedK t(c->timer, "k_probe");
 	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p,
 						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->dIndexedBits.p, c->dProbe.p,
-						 cntA.p, cntB.p); }
+						 c->dCntA.p, c->dCntB.p); }
 	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, cntA.p, c->dHitOff.p, nq);
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, cntB.p, c->dFiltOff.p, nq); }
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }
 	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
 	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
 	out->seed_hits = nHits;
@@ -799,20 +669,19 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	  hipLaunchKernelGGL(k_sort_hits, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
 						 c->dHitVal.p, nq); }
 	{ ScopedK t(c->timer, "k_group_count");
-	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, groupCnt.p); }
+	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, groupCnt.p, groupOff.p, nq); }
-	const u64 nGroups = fetchScalar(c, groupOff.p + nq);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
+	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
+	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "batch too large: split the query list"};
 	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
-	c->dScore.reserve(nHits + 1); c->dBack.reserve(nHits + 1); c->dOrder.reserve(nHits + 1);
 	c->dCand.reserve(nHits + 1);
-	DevBuf<PrimRec> prim, primOut;
-	DevBuf<u32> primFlag;
-	DevBuf<unsigned long long> counters;
-	prim.alloc(nGroups + 1); primFlag.alloc(nGroups + 1); counters.alloc(2);
-	HIP_CHECK(hipMemsetAsync(counters.p, 0, 16, s));
+	c->dPrim.reserve((nGroups + 1) * sizeof(PrimRec));
+	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
+	c->dListSmall.reserve(nGroups + 1); c->dListBig.reserve(nGroups + 1);
+	PrimRec* prim = (PrimRec*)c->dPrim.p;
 	{ ScopedK t(c->timer, "k_group_fill");
-	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, groupOff.p, c->dGroupStart.p,
+	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
 						 c->dGroupQuery.p); }
 	ChainParams cp;
 	cp.k = k; cp.maxJump = p->max_jump; cp.minOverlap = p->min_overlap; cp.maxOverhang = p->max_overhang;
@@ -822,98 +691,152 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
 	}
 	cp.firstId = c->firstId;
-	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "batch too large: split the query list"};
+	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
 	if (nGroups)
 	{
 		// smallest group size that can still have >= minUnique distinct query positions
 		u32 minSize = 0;
 		while ((float)minSize < cp.minUnique) ++minSize;
-		DevBuf<u32> listSmall, listBig, listCnt;
-		listSmall.alloc(nGroups); listBig.alloc(nGroups); listCnt.alloc(2);
-		HIP_CHECK(hipMemsetAsync(listCnt.p, 0, 8, s));
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
 		{ ScopedK t(c->timer, "k_group_classify");
 		  hipLaunchKernelGGL(k_group_classify, (unsigned)((nGroups + WG - 1) / WG), WG, 0, s, nGroups, nHits,
-							 c->dGroupStart.p, minSize, listSmall.p, listBig.p, listCnt.p, primFlag.p); }
+							 c->dGroupStart.p, minSize, c->dListSmall.p, c->dListBig.p, c->dListCnt.p,
+							 c->dPrimFlag.p, c->dDpSize.p); }
 		u32 hc[2];
-		HIP_CHECK(hipMemcpyAsync(hc, listCnt.p, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 		if (hc[0])
 		{
 			ScopedK t(c->timer, "k_chain_wave<lds>");
 			hipLaunchKernelGGL(k_chain_wave<true>, (hc[0] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
-							   cp, listSmall.p, hc[0], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
-							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, c->dScore.p, c->dBack.p, (u32*)nullptr,
-							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim.p, primFlag.p, counters.p);
+							   cp, c->dListSmall.p, hc[0], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
+							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, (i32*)nullptr, (i32*)nullptr, (u32*)nullptr,
+							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p, c->dDpSize.p);
 		}
 		if (hc[1])
 		{
 			c->dTmp32.reserve(3 * nHits + 3);
+			c->dScore.reserve(nHits + 1); c->dBack.reserve(nHits + 1);
 			ScopedK t(c->timer, "k_chain_wave<global>");
 			hipLaunchKernelGGL(k_chain_wave<false>, (hc[1] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
-							   cp, listBig.p, hc[1], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
+							   cp, c->dListBig.p, hc[1], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
 							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, c->dScore.p, c->dBack.p, c->dTmp32.p,
-							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim.p, primFlag.p, counters.p);
+							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p, c->dDpSize.p);
 		}
-		HIP_CHECK(hipStreamSynchronize(s));
 	}
 	{ ScopedK t(c->timer, "k_prim_count");
-	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, groupOff.p, primFlag.p, primCnt.p); }
+	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
+						 c->dDpGroups.p, c->dDpElems.p); }
 	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, primCnt.p, primOff.p, nq); }
-	const u64 nPrim = fetchScalar(c, primOff.p + nq);
-	primOut.alloc(nPrim + 1);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dPrimCnt.p, c->dPrimOff.p, nq); }
+	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
+	c->dPrimOut.reserve((nPrim + 1) * sizeof(PrimRec));
 	{ ScopedK t(c->timer, "k_prim_gather");
-	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, groupOff.p, primFlag.p, prim.p, primOff.p, primOut.p); }
-	std::vector<PrimRec> hPrim(nPrim);
-	std::vector<u64> hPrimOff(nq + 1);
-	unsigned long long hCnt[2];
-	if (nPrim) HIP_CHECK(hipMemcpyAsync(hPrim.data(), primOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(hPrimOff.data(), primOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipMemcpyAsync(hCnt, counters.p, 16, hipMemcpyDeviceToHost, s));
+	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, prim, c->dPrimOff.p,
+						 (PrimRec*)c->dPrimOut.p); }
+	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
+	c->hOff.reserve(3 * (size_t)(nq + 1));
+	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
+	const u64* hPrimOff = c->hOff.p;
+	const u64* hDpG = c->hOff.p + (nq + 1);
+	const u64* hDpE = c->hOff.p + 2 * (size_t)(nq + 1);
+	{ ScopedK t(c->timer, "copy_results_d2h");
+	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p, c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s)); }
 	HIP_CHECK(hipEventRecord(evB, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	out->dp_groups = hCnt[0];
-	out->dp_elements = hCnt[1];
+	out->dp_groups = 0; out->dp_elements = 0;
+	for (u32 i = 0; i < nq; ++i) { out->dp_groups += hDpG[i]; out->dp_elements += hDpE[i]; }
 
 	// ---- host shim: floats with the host libm, the gate, prefix rule, window stats ----
+	// two passes over the queries, both fanned out over host threads: (1) divergence,
+	// gate and per-query counts, (2) after a prefix sum, the records themselves
 	const float sampleRate = c->sampleRate;
 	const float maxDiv = p->max_divergence;
 	const int STAT_WND = 10000;
-	own->recs.reserve(nPrim);
-	struct Wnd { i32 range; float div; };
-	std::vector<Wnd> wnd;
+	std::vector<float> div(nPrim);
+	std::vector<uint8_t> keep(nPrim, 0);
+	std::vector<u32> nStat(nq, 0);
+	std::vector<std::vector<float>> statVals;
+	unsigned nThreads = std::thread::hardware_concurrency();
+	nThreads = std::max(1u, std::min(nThreads, 32u));
+	if (nPrim < 20000) nThreads = 1;
+	statVals.resize(nThreads);
+	std::vector<std::vector<u32>> statQ(nThreads);
+	auto pass1 = [&](unsigned t)
+	{
+		struct Wnd { i32 range; float div; };
+		std::vector<Wnd> wnd;
+		const u32 q0 = (u32)((u64)nq * t / nThreads), q1 = (u32)((u64)nq * (t + 1) / nThreads);
+		for (u32 qi = q0; qi < q1; ++qi)
+		{
+			const i32 curLen = c->hLen[hq[qi] >> 1];
+			wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
+			size_t detected = 0;
+			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
+			{
+				// groups are visited in ascending extId; the limit is tested at each group
+				// start against the overlaps accepted so far (overlap.cpp:218-219)
+				if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
+				const PrimRec& r = hPrim[j];
+				// overlap.cpp:414-423
+				float normLen = std::max(r.curEnd - r.curBegin, r.extEnd - r.extBegin) - r.filtered;
+				float matchRate = (float)r.chainLength * sampleRate / normLen;
+				matchRate = std::min(matchRate, 1.0f);
+				const float d = std::log(1 / matchRate) / k;
+				div[j] = d;
+				if (d < maxDiv) { keep[j] = 1; ++detected; }
+				const size_t w = r.curBegin / STAT_WND;
+				if (r.curEnd - r.curBegin > wnd[w].range) { wnd[w].range = r.curEnd - r.curBegin; wnd[w].div = d; }
+			}
+			own->queryOff[qi + 1] = detected;
+			u32 ns = 0;
+			for (auto& w : wnd) if (w.range > 0) { statVals[t].push_back(w.div); ++ns; }
+			nStat[qi] = ns;
+		}
+	};
+	auto runThreads = [&](const std::function<void(unsigned)>& fn)
+	{
+		if (nThreads == 1) { fn(0); return; }
+		std::vector<std::thread> pool;
+		for (unsigned t = 0; t < nThreads; ++t) pool.emplace_back(fn, t);
+		for (auto& th : pool) th.join();
+	};
+	runThreads(pass1);
+	own->queryOff[0] = 0;
 	for (u32 qi = 0; qi < nq; ++qi)
 	{
-		own->queryOff[qi] = own->recs.size();
-		own->statOff[qi] = own->stats.size();
-		const i32 curLen = c->hLen[hq[qi] >> 1];
-		wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
-		size_t detected = 0;
-		for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
-		{
-			// groups are visited in ascending extId; the limit is tested at each group
-			// start against the overlaps accepted so far (overlap.cpp:218-219)
-			if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
-			const PrimRec& r = hPrim[j];
-			fg_overlap_rec o;
-			o.cur_id = queryIds[qi]; o.ext_id = r.extId;
-			o.cur_begin = r.curBegin; o.cur_end = r.curEnd; o.cur_len = curLen;
-			o.ext_begin = r.extBegin; o.ext_end = r.extEnd; o.ext_len = r.extLen;
-			o.score = r.score; o.chain_length = r.chainLength; o.filtered_positions = r.filtered;
-			o.edit_distance = r.editDistance; o.hpc_len_cur = r.hpcLenCur; o.hpc_len_ext = r.hpcLenExt;
-			// overlap.cpp:414-423
-			float normLen = std::max(o.cur_end - o.cur_begin, o.ext_end - o.ext_begin) - r.filtered;
-			float matchRate = (float)r.chainLength * sampleRate / normLen;
-			matchRate = std::min(matchRate, 1.0f);
-			o.seq_divergence = std::log(1 / matchRate) / k;
-			if (o.seq_divergence < maxDiv) { own->recs.push_back(o); ++detected; }
-			const size_t w = o.cur_begin / STAT_WND;
-			if (o.cur_end - o.cur_begin > wnd[w].range) { wnd[w].range = o.cur_end - o.cur_begin; wnd[w].div = o.seq_divergence; }
-		}
-		for (auto& w : wnd) if (w.range > 0) own->stats.push_back(w.div);
+		own->queryOff[qi + 1] += own->queryOff[qi];
+		own->statOff[qi + 1] = own->statOff[qi] + nStat[qi];
 	}
-	own->queryOff[nq] = own->recs.size();
-	own->statOff[nq] = own->stats.size();
+	own->recs.resize(own->queryOff[nq]);
+	own->stats.reserve(own->statOff[nq]);
+	for (unsigned t = 0; t < nThreads; ++t) own->stats.insert(own->stats.end(), statVals[t].begin(), statVals[t].end());
+	auto pass2 = [&](unsigned t)
+	{
+		const u32 q0 = (u32)((u64)nq * t / nThreads), q1 = (u32)((u64)nq * (t + 1) / nThreads);
+		for (u32 qi = q0; qi < q1; ++qi)
+		{
+			const i32 curLen = c->hLen[hq[qi] >> 1];
+			fg_overlap_rec* dst = own->recs.data() + own->queryOff[qi];
+			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
+			{
+				if (!keep[j]) continue;
+				const PrimRec& r = hPrim[j];
+				fg_overlap_rec o;
+				o.cur_id = queryIds[qi]; o.ext_id = r.extId;
+				o.cur_begin = r.curBegin; o.cur_end = r.curEnd; o.cur_len = curLen;
+				o.ext_begin = r.extBegin; o.ext_end = r.extEnd; o.ext_len = r.extLen;
+				o.score = r.score; o.seq_divergence = div[j];
+				o.chain_length = r.chainLength; o.filtered_positions = r.filtered;
+				o.edit_distance = r.editDistance; o.hpc_len_cur = r.hpcLenCur; o.hpc_len_ext = r.hpcLenExt;
+				*dst++ = o;
+			}
+		}
+	};
+	runThreads(pass2);
 	out->n_recs = own->recs.size();
 	out->query_off = own->queryOff.data();
 	out->recs = own->recs.data();

@@ -114,15 +114,42 @@ class IndexExport:
         self.keys, self.key_off, self.entries, self.repetitive = keys, key_off, entries, repetitive
 
 
-class OverlapResult:
-    """Flat result of one batched ``getSeqOverlaps`` call."""
+class _Arena:
+    """Owns one fg_overlap_batch; released when the last array view is gone."""
 
-    def __init__(self, query_ids, query_off, recs, stat_off, stats, batch):
-        self.query_ids, self.query_off, self.recs = query_ids, query_off, recs
-        self.stat_off, self.stats = stat_off, stats
-        self.query_bp, self.query_kmers = batch.query_bp, batch.query_kmers
-        self.seed_hits, self.dp_groups, self.dp_elements = batch.seed_hits, batch.dp_groups, batch.dp_elements
-        self.device_seconds = batch.device_seconds
+    def __init__(self, lib, batch):
+        self.lib, self.batch = lib, batch
+
+    def __del__(self):
+        try:
+            self.lib.fg_release_batch(C.byref(self.batch))
+        except Exception:
+            pass
+
+    def view(self, ptr, ctype, count, dtype):
+        if not count:
+            return np.empty(0, dtype)
+        buf = (ctype * count).from_address(ptr)
+        buf._arena = self            # the numpy view keeps buf (its base), buf keeps the arena
+        return np.frombuffer(buf, dtype=dtype)
+
+
+class OverlapResult:
+    """Flat result of one batched ``getSeqOverlaps`` call.  The arrays are zero-copy
+    views of the library-owned arena; the arena is released when the last view dies."""
+
+    def __init__(self, lib, query_ids, batch):
+        arena = _Arena(lib, batch)
+        b = batch
+        nq = len(query_ids)
+        self.query_ids = query_ids
+        self.query_off = arena.view(b.query_off, C.c_uint64, nq + 1, np.uint64)
+        self.stat_off = arena.view(b.div_stats_off, C.c_uint64, nq + 1, np.uint64)
+        self.recs = arena.view(b.recs, C.c_uint8, b.n_recs * REC_DTYPE.itemsize, REC_DTYPE)
+        self.stats = arena.view(b.div_stats, C.c_float, b.n_div_stats, np.float32)
+        self.query_bp, self.query_kmers = b.query_bp, b.query_kmers
+        self.seed_hits, self.dp_groups, self.dp_elements = b.seed_hits, b.dp_groups, b.dp_elements
+        self.device_seconds = b.device_seconds
 
     def of(self, i):
         return self.recs[int(self.query_off[i]):int(self.query_off[i + 1])]
@@ -278,22 +305,7 @@ class OverlapDetector:
         L = self.ctx.L
         self.ctx._check(L.fg_overlaps(self.ctx.h, C.byref(self.p), q.ctypes.data, len(q), maxOverlaps,
                                       int(bool(forceLocal)), C.byref(b)))
-        try:
-            nq = len(q)
-            qo = np.ctypeslib.as_array(C.cast(b.query_off, C.POINTER(C.c_uint64)), (nq + 1,)).copy()
-            so = np.ctypeslib.as_array(C.cast(b.div_stats_off, C.POINTER(C.c_uint64)), (nq + 1,)).copy()
-            if b.n_recs:
-                raw = C.string_at(b.recs, b.n_recs * REC_DTYPE.itemsize)
-                recs = np.frombuffer(raw, dtype=REC_DTYPE).copy()
-            else:
-                recs = np.empty(0, REC_DTYPE)
-            if b.n_div_stats:
-                stats = np.ctypeslib.as_array(C.cast(b.div_stats, C.POINTER(C.c_float)), (b.n_div_stats,)).copy()
-            else:
-                stats = np.empty(0, np.float32)
-            return OverlapResult(q, qo, recs, so, stats, b)
-        finally:
-            L.fg_release_batch(C.byref(b))
+        return OverlapResult(L, q, b)
 
 
 def complement(recs: np.ndarray) -> np.ndarray:
@@ -325,7 +337,7 @@ class OverlapContainer:
     def quickSeqOverlaps(self, readId: int, maxOverlaps: int = 0, forceLocal: bool = False):
         res = self.det.getSeqOverlapsBatch([readId], forceLocal, maxOverlaps)
         self.divergence_stats.extend(res.stats.tolist())
-        return res.recs
+        return res.recs.copy()
 
     def prefetch(self, readIds):
         fwd = sorted({int(r) & ~1 for r in readIds if (int(r) & ~1) not in self._cache})
