@@ -178,6 +178,7 @@ struct fg_ctx {
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListCnt;
 	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
+	DevBuf<char> dSortTasks;
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;
 

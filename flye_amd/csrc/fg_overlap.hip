@@ -189,18 +189,104 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 	}
 }
 
-// ---- exact std::sort order, one wave per query (fg_wavesort.h) ---------------------
-__global__ void k_sort_hits(const u64* __restrict__ hitOff, u64* __restrict__ hitKey,
-							u32* __restrict__ hitVal, u32 nq)
+// ---- exact std::sort order of every query's hits (fg_wavesort.h) ---------------------
+// Two kernels.  k_sort_top: one wave per query runs the top of the introsort recursion in
+// global memory (L2-resident) until a piece fits SORT_CAP elements and queues it;
+// k_sort_lds: one wave per queued piece finishes it entirely in LDS.
+#define SORT_CAP 512
+#define SORT_LDS_WAVES 4
+struct SortTask { u64 start; u32 n; u32 depth; };
+
+__global__ void k_sort_top(const u64* __restrict__ hitOff, u64* __restrict__ hitKey, u32* __restrict__ hitVal,
+						   u32 nq, u32* __restrict__ posScratch, u64 nHits, SortTask* __restrict__ tasks,
+						   u32 taskCap, u32* __restrict__ taskCount)
 {
 	__shared__ int stack[WG / 64][3 * 40];
 	__shared__ int small[WG / 64][3 * 8];
 	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
 	const u32 q = blockIdx.x * (WG / 64) + wv;
 	if (q >= nq) return;
 	const u64 base = hitOff[q];
 	const u64 n64 = hitOff[q + 1] - base;
-	wsort::wave_sort<u64>(hitKey + base, hitVal + base, (int)n64, stack[wv], small[wv]);
+	if (n64 < 2) return;
+	u64* K = hitKey + base;
+	u32* V = hitVal + base;
+	u32* posL = posScratch + base;
+	u32* posR = posScratch + nHits + base;
+	int* stk = stack[wv];
+	int sp = 0;
+	int first = 0, last = (int)n64, depth = 2 * fgsort::floor_log2_((int)n64);
+	while (true)
+	{
+		bool handled = false;
+		if (last - first <= SORT_CAP)
+		{
+			if (last - first >= 2)
+			{
+				u32 idx = 0;
+				if (lane == 0) idx = atomicAdd(taskCount, 1u);
+				idx = __shfl(idx, 0);
+				if (idx < taskCap)
+				{
+					if (lane == 0) tasks[idx] = SortTask{base + (u64)first, (u32)(last - first), (u32)depth};
+				}
+				else	// queue full: finish the piece here (slow path)
+					wsort::wave_sort<u64, u32>(K, V, last - first, posL, posR, stk + sp, small[wv], first, depth);
+			}
+			handled = true;
+		}
+		else if (depth == 0)
+		{
+			wsort::wave_mem_fence();
+			if (lane == 0) { wsort::PtrAcc<u64> acc{K, V}; fgsort::heap_sort_(acc, first, last); }
+			wsort::wave_mem_fence();
+			handled = true;
+		}
+		if (!handled)
+		{
+			--depth;
+			const int cut = wsort::partition_big<u64, u32>(K, V, first, last, posL + first, posR + first);
+			if (cut - first < last - cut)
+			{
+				stk[sp++] = cut; stk[sp++] = last; stk[sp++] = depth;
+				last = cut;
+			}
+			else
+			{
+				stk[sp++] = first; stk[sp++] = cut; stk[sp++] = depth;
+				first = cut;
+			}
+			continue;
+		}
+		if (sp == 0) break;
+		depth = stk[--sp]; last = stk[--sp]; first = stk[--sp];
+	}
+}
+
+__global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
+k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount, u32 taskCap,
+		   u64* __restrict__ hitKey, u32* __restrict__ hitVal)
+{
+	__shared__ u64 sK[SORT_LDS_WAVES][SORT_CAP];
+	__shared__ u32 sV[SORT_LDS_WAVES][SORT_CAP];
+	__shared__ unsigned short sPL[SORT_LDS_WAVES][SORT_CAP], sPR[SORT_LDS_WAVES][SORT_CAP];
+	__shared__ int stack[SORT_LDS_WAVES][3 * 40];
+	__shared__ int small[SORT_LDS_WAVES][3 * 8];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	u32 nTasks = *taskCount;
+	if (nTasks > taskCap) nTasks = taskCap;
+	const u32 ti = blockIdx.x * SORT_LDS_WAVES + wv;
+	if (ti >= nTasks) return;
+	const SortTask t = tasks[ti];
+	u64* K = hitKey + t.start;
+	u32* V = hitVal + t.start;
+	const int n = (int)t.n;
+	for (int i = lane; i < n; i += 64) { sK[wv][i] = K[i]; sV[wv][i] = V[i]; }
+	wsort::wave_mem_fence();
+	wsort::wave_sort<u64, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+	for (int i = lane; i < n; i += 64) { K[i] = sK[wv][i]; V[i] = sV[wv][i]; }
 }
 
 // ---- target groups ---------------------------------------------------------------------
@@ -314,7 +400,7 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 			 const u32* __restrict__ query, const i32* __restrict__ len,
 			 u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ gScore,
-			 i32* __restrict__ gBack, u32* __restrict__ gAux /* 3 u32 per hit */,
+			 i32* __restrict__ gBack, u32* __restrict__ gAux /* 5 u32 per hit */,
 			 int4* __restrict__ cand, const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
 			 PrimRec* __restrict__ prim, u32* __restrict__ primFlag, u32* __restrict__ dpSize)
 {
@@ -324,6 +410,8 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	__shared__ i32 sBack[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
 	__shared__ u32 sOKey[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
 	__shared__ u32 sOVal[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ unsigned short sPL[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
+	__shared__ unsigned short sPR[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
 	__shared__ int stack[CHAIN_WAVES][3 * 40];
 	__shared__ int small[CHAIN_WAVES][3 * 8];
 	const int wv = threadIdx.x >> 6;
@@ -346,7 +434,7 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	}
 	else
 	{
-		cur = gAux + 3 * g0; okey = cur + n; oval = okey + n;
+		cur = gAux + 5 * g0; okey = cur + n; oval = okey + n;	// + 2n of partition scratch behind oval
 		ext = hitVal + g0; score = gScore + g0; back = gBack + g0;
 	}
 
@@ -387,7 +475,11 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	wsort::wave_mem_fence();
 
 	const bool extSorted = extLen > curLen;
-	if (extSorted && !(P.ablate & 4)) wsort::wave_sort<u32>(ext, cur, n, stack[wv], small[wv]);	// overlap.cpp:269-275
+	if (extSorted && !(P.ablate & 4))	// overlap.cpp:269-275
+	{
+		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(ext, cur, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		else wsort::wave_sort<u32, u32>(ext, cur, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+	}
 
 	// chaining DP (overlap.cpp:266-323).  Lane L keeps element i-1-L of the scan in
 	// registers (a window sliding by one lane per i), so the usual look-back never
@@ -446,7 +538,11 @@ k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
 	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
 	wsort::wave_mem_fence();
-	if (!(P.ablate & 2)) wsort::wave_sort<u32>(okey, oval, n, stack[wv], small[wv]);
+	if (!(P.ablate & 2))
+	{
+		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+	}
 
 	if (lane != 0 || (P.ablate & 8)) return;
 	// backtrack, overlapTest, primary selection: short pointer chases, one lane
@@ -593,13 +689,21 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 {
 	hipStream_t s = c->stream;
 	const u64 n = segOff[nSeg];
-	DevBuf<u64> dK, dOff; DevBuf<u32> dV;
-	dK.alloc(n + 1); dV.alloc(n + 1); dOff.alloc(nSeg + 1);
+	DevBuf<u64> dK, dOff; DevBuf<u32> dV, dPos, dCnt; DevBuf<SortTask> dTasks;
+	// a deliberately small queue so that the "queue full" path is exercised too
+	const u32 taskCap = (u32)(n / 64 + nSeg / 2 + 16);
+	dK.alloc(n + 1); dV.alloc(n + 1); dOff.alloc(nSeg + 1); dPos.alloc(2 * n + 2); dCnt.alloc(1); dTasks.alloc(taskCap);
 	HIP_CHECK(hipMemcpyAsync(dK.p, keys, n * 8, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dV.p, vals, n * 4, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dOff.p, segOff, (nSeg + 1) * 8ULL, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemsetAsync(dCnt.p, 0, 4, s));
 	if (nSeg)
-		hipLaunchKernelGGL(k_sort_hits, (nSeg + WG / 64 - 1) / (WG / 64), WG, 0, s, dOff.p, dK.p, dV.p, nSeg);
+	{
+		hipLaunchKernelGGL(k_sort_top, (nSeg + WG / 64 - 1) / (WG / 64), WG, 0, s, dOff.p, dK.p, dV.p, nSeg, dPos.p, n,
+						   dTasks.p, taskCap, dCnt.p);
+		hipLaunchKernelGGL(k_sort_lds, (taskCap + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+						   dTasks.p, dCnt.p, taskCap, dK.p, dV.p);
+	}
 	HIP_CHECK(hipMemcpyAsync(keys, dK.p, n * 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(vals, dV.p, n * 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -665,9 +769,24 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	{ ScopedK t(c->timer, "k_fill");
 	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
 						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
-	{ ScopedK t(c->timer, "k_sort_hits");
-	  hipLaunchKernelGGL(k_sort_hits, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
-						 c->dHitVal.p, nq); }
+	{
+		const u64 cap64 = nHits / 8 + 4ULL * nq + 1024;
+		const u32 taskCap = (u32)std::min<u64>(cap64, 0x7fffffffULL);
+		c->dTmp32.reserve(2 * nHits + 2);
+		c->dSortTasks.reserve((size_t)taskCap * sizeof(SortTask));
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
+		{ ScopedK t(c->timer, "k_sort_top");
+		  hipLaunchKernelGGL(k_sort_top, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
+							 c->dHitVal.p, nq, c->dTmp32.p, nHits, (SortTask*)c->dSortTasks.p, taskCap, c->dListCnt.p); }
+		u32 nTasks = fetchScalar(c, c->dListCnt.p);
+		nTasks = std::min(nTasks, taskCap);
+		if (nTasks)
+		{
+			ScopedK t(c->timer, "k_sort_lds");
+			hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+							   (const SortTask*)c->dSortTasks.p, c->dListCnt.p, taskCap, c->dHitKey.p, c->dHitVal.p);
+		}
+	}
 	{ ScopedK t(c->timer, "k_group_count");
 	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");
@@ -692,6 +811,14 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	cp.firstId = c->firstId;
 	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
+	{
+		static int lastAblate = 0;
+		if (cp.ablate != lastAblate)
+		{
+			HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(wsort::g_ablate), &cp.ablate, sizeof(int)));
+			lastAblate = cp.ablate;
+		}
+	}
 	if (nGroups)
 	{
 		// smallest group size that can still have >= minUnique distinct query positions
@@ -715,7 +842,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		}
 		if (hc[1])
 		{
-			c->dTmp32.reserve(3 * nHits + 3);
+			c->dTmp32.reserve(5 * nHits + 5);
 			c->dScore.reserve(nHits + 1); c->dBack.reserve(nHits + 1);
 			ScopedK t(c->timer, "k_chain_wave<global>");
 			hipLaunchKernelGGL(k_chain_wave<false>, (hc[1] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,

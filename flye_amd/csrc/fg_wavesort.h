@@ -20,6 +20,10 @@
 
 namespace wsort {
 
+// timing experiments only (FG_ABLATE env): 16 = skip the register quicksort phase of
+// sort_small, 32 = skip its final placement, 64 = skip partition pass B
+__device__ int g_ablate = 0;
+
 template <class KT>
 struct KV { KT k; u32 v; };
 
@@ -53,6 +57,20 @@ __device__ __forceinline__ u64 shflk(u64 v, int src)
 }
 __device__ __forceinline__ u32 shflk(u32 v, int src) { return __shfl(v, src); }
 
+// whole-wave rotation by one lane (DPP wave_ror:1 = 0x13C, wave_rol:1 = 0x134)
+template <int CTRL>
+__device__ __forceinline__ u32 rot_key(u32 v)
+{
+	return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ u64 rot_key(u64 v)
+{
+	const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, 0xf, 0xf, false);
+	const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, 0xf, 0xf, false);
+	return ((u64)hi << 32) | lo;
+}
+
 // data written by some lanes of this wave is re-read by other lanes
 __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -65,8 +83,12 @@ __device__ __forceinline__ int median3(KT ka, KT kb, KT kc)
 	return 1;
 }
 
-// Hoare partition of one element per lane, lanes [lo,hi) take part; returns the cut
-// lane; key/val are replaced by the lane's new element.
+// Hoare partition of one element per lane, lanes [lo,hi) take part (at most 63 lanes,
+// so stop ranks stay below 63 and lane 63 can serve as the dump target of the pushes);
+// returns the cut lane; key/val are replaced by the lane's new element.
+// Stops are matched through the LDS crossbar instead of bit-select arithmetic: every
+// left stop pushes its lane id to lane rankL, every right stop to lane rankR (counted
+// from the top); lane r then holds the pair (l_{r+1}, r_{r+1}) and tests l < r.
 template <class KT>
 __device__ __forceinline__ int lane_partition(KT& key, u32& val, int lo, int hi, KT pk)
 {
@@ -76,20 +98,22 @@ __device__ __forceinline__ int lane_partition(KT& key, u32& val, int lo, int hi,
 	const bool le = in && key <= pk;
 	const u64 mL = __ballot(ge), mR = __ballot(le);
 	const int cL = __popcll(mL), cR = __popcll(mR);
-	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	const u64 above = (lane == 63) ? 0ULL : (~0ULL << (lane + 1));
-	const int rankL = __popcll(mL & below);
-	const int rankR = __popcll(mR & above);
-	const int partnerOfL = (ge && rankL < cR) ? nth_set_bit_desc(mR, rankL) : -1;
-	const bool swapL = ge && partnerOfL > lane;
-	const int K = __popcll(__ballot(swapL));
+	const int rankL = __builtin_amdgcn_mbcnt_hi((u32)(mL >> 32), __builtin_amdgcn_mbcnt_lo((u32)mL, 0));
+	const int belowR = __builtin_amdgcn_mbcnt_hi((u32)(mR >> 32), __builtin_amdgcn_mbcnt_lo((u32)mR, 0));
+	const int rankR = cR - 1 - belowR;	// meaningful on right stops only
+	const int idxL = __builtin_amdgcn_ds_permute((ge ? rankL : 63) << 2, lane);
+	const int idxR = __builtin_amdgcn_ds_permute((le ? rankR : 63) << 2, lane);
+	const int nPairs = cL < cR ? cL : cR;
+	const int K = __popcll(__ballot(lane < nPairs && idxL < idxR));	// l_k < r_k is monotone in k
+	const int partL = __builtin_amdgcn_ds_bpermute((ge ? rankL : lane) << 2, idxR);
+	const int partR = __builtin_amdgcn_ds_bpermute((le ? rankR : lane) << 2, idxL);
 	int src = lane;
-	if (swapL) src = partnerOfL;
-	else if (le && rankR < K) src = nth_set_bit(mL, rankR);
+	if (ge && rankL < K) src = partL;
+	else if (le && rankR < K) src = partR;
 	key = shflk(key, src);
 	val = __shfl(val, src);
-	const int lK1 = (cL > K) ? nth_set_bit(mL, K) : 0x7fffffff;
-	const int rK = (K >= 1) ? nth_set_bit_desc(mR, K - 1) : hi;
+	const int lK1 = (cL > K) ? __builtin_amdgcn_readlane(idxL, __builtin_amdgcn_readfirstlane(K)) : 0x7fffffff;
+	const int rK = (K >= 1) ? __builtin_amdgcn_readlane(idxR, __builtin_amdgcn_readfirstlane(K - 1)) : hi;
 	return lK1 < rK ? lK1 : rK;
 }
 
@@ -105,7 +129,7 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	int a = 0, b = n, d = depth;
 	while (true)
 	{
-		while (b - a > 16)
+		while (b - a > 16 && !(g_ablate & 16))
 		{
 			if (d == 0)
 			{
@@ -132,20 +156,42 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 		if (sp == 0) break;
 		d = stk[--sp]; b = stk[--sp]; a = stk[--sp];
 	}
-	int rank = 0;
-	for (int j = 0; j < n; ++j)
+	// final insertion sort = stable placement.  After the quicksort phase every element
+	// sits inside its own <= 16-element leaf and the leaves are mutually ordered, so the
+	// target is lane - #(greater keys among the 15 lanes below) + #(smaller keys among the
+	// 15 lanes above).  Neighbours arrive by DPP wave rotations (no LDS traffic); the lane
+	// id travels with the key, so the count does not depend on the rotation direction.
+	int pos = lane;
+	if (!(g_ablate & 32))
 	{
-		const KT kj = shflk(key, j);
-		rank += (kj < key) || (kj == key && j < lane);
+		KT rk = key; int rid = lane;
+		for (int d = 0; d < 15; ++d)
+		{
+			rk = rot_key<0x13C>(rk); rid = __builtin_amdgcn_update_dpp(0, rid, 0x13C, 0xf, 0xf, false);
+			const int dist = rid - lane;
+			if (rid < n && dist >= -15 && dist < 0) pos -= (rk > key);
+			if (rid < n && dist > 0 && dist <= 15) pos += (rk < key);
+		}
+		rk = key; rid = lane;
+		for (int d = 0; d < 15; ++d)
+		{
+			rk = rot_key<0x134>(rk); rid = __builtin_amdgcn_update_dpp(0, rid, 0x134, 0xf, 0xf, false);
+			const int dist = rid - lane;
+			if (rid < n && dist >= -15 && dist < 0) pos -= (rk > key);
+			if (rid < n && dist > 0 && dist <= 15) pos += (rk < key);
+		}
 	}
 	wave_mem_fence();
-	if (lane < n) { K[first + rank] = key; V[first + rank] = val; }
+	if (lane < n) { K[first + pos] = key; V[first + pos] = val; }
 }
 
-// segment of > 64 elements in memory: pivot to first, the partition streamed in
-// chunks of <= 64 from both ends, the last <= 64 untouched elements in registers
-template <class KT>
-__device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last)
+// segment of > 64 elements in memory: pivot to first, then the closed form of the
+// Hoare loop.  Pass A lists the stop positions of both pointers (posL: keys >= pivot,
+// left to right; posR: keys <= pivot, left to right, read back to front); pass B swaps
+// pair k while l_k < r_k.  No step depends on the data of the previous tile, so the
+// loads of several tiles are in flight together.  posL/posR: >= (last-first) entries each.
+template <class KT, class PT>
+__device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last, PT* posL, PT* posR)
 {
 	const int lane = threadIdx.x & 63;
 	const int mid = first + (last - first) / 2;
@@ -153,7 +199,6 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last)
 	const int m3 = median3(ka, kb, kc);
 	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
 	const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
-	wave_mem_fence();
 	if (lane == 0)
 	{
 		const KT k0 = K[first]; const u32 v0 = V[first]; const u32 vp = V[pick];
@@ -161,63 +206,73 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last)
 		K[pick] = k0; V[pick] = v0;
 	}
 	wave_mem_fence();
-	int f = first + 1, l = last;	// untouched window [f, l)
-	while (l - f > 64)
+	const int base = first + 1;
+	const int m = last - base;
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+	int cL = 0, cR = 0;
+	int t = 0;
+	for (; t + 256 <= m; t += 256)
 	{
-		const int W = l - f;
-		const int wl = W / 2 < 64 ? W / 2 : 64;
-		const bool valid = lane < wl;
-		const int iL = f + lane, iR = l - 1 - lane;
-		KT kL = 0, kR = 0; u32 vL = 0, vR = 0;
-		if (valid) { kL = K[iL]; vL = V[iL]; kR = K[iR]; vR = V[iR]; }
-		const bool geL = valid && kL >= pk;
-		const bool leR = valid && kR <= pk;
-		const u64 mL = __ballot(geL), mR = __ballot(leR);
-		const int cL = __popcll(mL), cR = __popcll(mR);
-		const int m = cL < cR ? cL : cR;
-		if (m > 0)
-		{
-			const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-			const int rankL = __popcll(mL & below), rankR = __popcll(mR & below);
-			if (geL && rankL < m)
-			{
-				const int dst = l - 1 - nth_set_bit(mR, rankL);
-				K[dst] = kL; V[dst] = vL;
-			}
-			if (leR && rankR < m)
-			{
-				const int dst = f + nth_set_bit(mL, rankR);
-				K[dst] = kR; V[dst] = vR;
-			}
-			const int lastL = nth_set_bit(mL, m - 1), lastR = nth_set_bit(mR, m - 1);
-			f = f + lastL + 1;
-			l = l - 1 - lastR;
-		}
-		else
-		{
-			if (cL == 0) f += wl;
-			if (cR == 0) l -= wl;
-		}
+		KT k0 = K[base + t + lane], k1 = K[base + t + 64 + lane], k2 = K[base + t + 128 + lane], k3 = K[base + t + 192 + lane];
+#define FG_TILE(kk, off) { \
+		const bool ge = kk >= pk, le = kk <= pk; \
+		const u64 mL = __ballot(ge), mR = __ballot(le); \
+		if (ge) posL[cL + __popcll(mL & below)] = (PT)(t + off + lane); \
+		if (le) posR[cR + __popcll(mR & below)] = (PT)(t + off + lane); \
+		cL += __popcll(mL); cR += __popcll(mR); }
+		FG_TILE(k0, 0) FG_TILE(k1, 64) FG_TILE(k2, 128) FG_TILE(k3, 192)
 	}
-	const int W = l - f;
-	KT key = lane < W ? K[f + lane] : (KT)0;
-	u32 val = lane < W ? V[f + lane] : 0u;
-	const KT key0 = key; const u32 val0 = val;
-	const int cutLane = lane_partition(key, val, 0, W, pk);
-	if (lane < W && (key != key0 || val != val0)) { K[f + lane] = key; V[f + lane] = val; }
+	for (; t < m; t += 64)
+	{
+		const int i = t + lane;
+		const bool valid = i < m;
+		const KT kk = valid ? K[base + i] : (KT)0;
+		const bool ge = valid && kk >= pk, le = valid && kk <= pk;
+		const u64 mL = __ballot(ge), mR = __ballot(le);
+		if (ge) posL[cL + __popcll(mL & below)] = (PT)i;
+		if (le) posR[cR + __popcll(mR & below)] = (PT)i;
+		cL += __popcll(mL); cR += __popcll(mR);
+	}
+#undef FG_TILE
 	wave_mem_fence();
-	return f + cutLane;
+	const int nPairs = cL < cR ? cL : cR;
+	int nSwap = 0;
+	for (int t2 = 0; t2 < ((g_ablate & 64) ? 0 : nPairs); t2 += 64)
+	{
+		const int kq = t2 + lane;
+		const bool valid = kq < nPairs;
+		const int a = valid ? (int)posL[kq] : 0;
+		const int b = valid ? (int)posR[cR - 1 - kq] : 0;
+		const bool sw = valid && a < b;
+		const u64 ms = __ballot(sw);
+		if (sw)
+		{
+			const KT xa = K[base + a], xb = K[base + b];
+			const u32 ya = V[base + a], yb = V[base + b];
+			K[base + a] = xb; V[base + a] = yb;
+			K[base + b] = xa; V[base + b] = ya;
+		}
+		nSwap += __popcll(ms);
+		if (ms != __ballot(valid)) break;	// l_k < r_k is monotone in k
+	}
+	wave_mem_fence();
+	const int lK1 = (nSwap < cL) ? (int)posL[nSwap] : 0x7fffffff;
+	const int rK = (nSwap >= 1) ? (int)posR[cR - nSwap] : m;
+	return base + (lK1 < rK ? lK1 : rK);
 }
 
-// std::sort(K[0..n), by key) with V carried along.  stk: >= 3*40 ints, sstk: >= 24
-// ints, both private to the calling wave.  All 64 lanes must call.
-template <class KT>
-__device__ __forceinline__ void wave_sort(KT* K, u32* V, int n, int* stk, int* sstk)
+// std::sort(K[first0 .. first0+n), by key) with V carried along.  stk: >= 3*40 ints,
+// sstk: >= 24 ints, posL/posR: >= n entries each, all private to the calling wave.
+// depth0 >= 0 continues an introsort whose depth budget is already partly spent.
+// All 64 lanes must call.
+template <class KT, class PT>
+__device__ __forceinline__ void wave_sort(KT* K, u32* V, int n, PT* posL, PT* posR, int* stk, int* sstk,
+										  int first0 = 0, int depth0 = -1)
 {
 	if (n < 2) return;
 	const int lane = threadIdx.x & 63;
 	int sp = 0;
-	int first = 0, last = n, depth = 2 * fgsort::floor_log2_(n);
+	int first = first0, last = first0 + n, depth = depth0 >= 0 ? depth0 : 2 * fgsort::floor_log2_(n);
 	while (true)
 	{
 		if (last - first <= 64)
@@ -233,7 +288,7 @@ __device__ __forceinline__ void wave_sort(KT* K, u32* V, int n, int* stk, int* s
 		else
 		{
 			--depth;
-			const int cut = partition_big(K, V, first, last);
+			const int cut = partition_big(K, V, first, last, posL, posR);
 			if (cut - first < last - cut)
 			{
 				stk[sp++] = cut; stk[sp++] = last; stk[sp++] = depth;
