@@ -179,6 +179,7 @@ struct fg_ctx {
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListCnt;
 	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
 	DevBuf<char> dSortTasks;
+	DevBuf<int> dEditScratch;
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;
 
@@ -266,6 +267,7 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
+void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out);

@@ -712,7 +712,6 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out)
 {
-	if (p->nucl_alignment) throw FgError{FG_ERR_UNSUPPORTED, "nucl_alignment (edlib divergence) is not built yet"};
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	c->timer.evs.clear();
@@ -861,6 +860,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	{ ScopedK t(c->timer, "k_prim_gather");
 	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, prim, c->dPrimOff.p,
 						 (PrimRec*)c->dPrimOut.p); }
+	if (p->nucl_alignment) fgEditDistances(c, (PrimRec*)c->dPrimOut.p, nPrim, p->use_hpc);
 	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
 	c->hOff.reserve(3 * (size_t)(nq + 1));
 	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
@@ -882,6 +882,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	// gate and per-query counts, (2) after a prefix sum, the records themselves
 	const float sampleRate = c->sampleRate;
 	const float maxDiv = p->max_divergence;
+	const bool nucl = p->nucl_alignment;
 	const int STAT_WND = 10000;
 	std::vector<float> div(nPrim);
 	std::vector<uint8_t> keep(nPrim, 0);
@@ -912,7 +913,9 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				float normLen = std::max(r.curEnd - r.curBegin, r.extEnd - r.extBegin) - r.filtered;
 				float matchRate = (float)r.chainLength * sampleRate / normLen;
 				matchRate = std::min(matchRate, 1.0f);
-				const float d = std::log(1 / matchRate) / k;
+				float d = std::log(1 / matchRate) / k;
+				if (nucl)	// alignment.cpp:244-245
+					d = (float)r.editDistance / std::max((size_t)r.hpcLenExt, (size_t)r.hpcLenCur);
 				div[j] = d;
 				if (d < maxDiv) { keep[j] = 1; ++detected; }
 				const size_t w = r.curBegin / STAT_WND;

@@ -113,7 +113,7 @@ struct fg_detector_params {
 	int32_t max_overhang;          /* 0 => _checkOverhang = false */
 	uint8_t keep_alignment;        /* kmerMatches output: FG_ERR_UNSUPPORTED if set */
 	uint8_t only_max_ext;          /* must be 1 for now */
-	uint8_t nucl_alignment;        /* edlib divergence (alignment.cpp:218-247) */
+	uint8_t nucl_alignment;        /* base-level divergence (alignment.cpp:218-247) */
 	uint8_t partition_bad_mappings;/* FG_ERR_UNSUPPORTED if set */
 	uint8_t use_hpc;
 	uint8_t pad_[3];

@@ -11,7 +11,7 @@ from helpers import (bits_to_float, case_queries, check_index_stats, golden_line
 
 pytestmark = pytest.mark.gpu
 
-RAW_CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local"]
+GOLDEN_CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max"]
 
 
 def _gpu_setup(rs, cfg):
@@ -37,7 +37,7 @@ def _same_index(a, b):
             and np.array_equal(a.entries, b.entries) and np.array_equal(a.repetitive, b.repetitive))
 
 
-@pytest.mark.parametrize("name", RAW_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_golden_reference_vectors(built, golden_cases, name):
     from flye_amd import config
     case = golden_cases[name]
@@ -58,18 +58,21 @@ def test_golden_reference_vectors(built, golden_cases, name):
     (2, "ont_raw", dict(max_overlaps=7, hp=50, tr=80)),
     (3, "pb_raw", dict(force_local=True, max_div=0.2)),
     (4, "pb_raw", dict(first_id=1000, rep=12)),
+    (5, "hifi", dict(preset="hifi", mixed=True, max_div=0.01, cov=20)),
+    (6, "hifi03", dict(preset="corrected", max_overlaps=9, hp=60, tr=60, cov=20)),
+    (7, "pb_raw", dict(preset="hifi", cov=20)),     # divergent pairs through the edit-distance kernel
 ])
 def test_against_oracle_variants(built, seed, kind, opts):
     from flye_amd import config, gpu, synth
     from oracle import oracle as O
-    rs = synth.simulate(seed=seed, genome_len=50_000, coverage=30, kind=kind,
+    rs = synth.simulate(seed=seed, genome_len=50_000, coverage=opts.get("cov", 30), kind=kind,
                         n_homopolymers=opts.get("hp", 8), n_tandems=opts.get("tr", 8),
                         n_repeat_families=opts.get("rep", 4)).filter_min_len(1000)
-    cfg = config.preset("raw")
+    cfg = config.preset(opts.get("preset", "raw"))
     first = opts.get("first_id", 0)
     ctx = gpu.Context(17, 0)
     ctx.set_reads(rs, first)
-    vi = gpu.VertexIndex(ctx, 1.0)
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
     gst = vi.build(cfg)
     det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
     det.p.max_divergence = opts.get("max_div", 1.0)
@@ -88,7 +91,7 @@ def test_against_oracle_variants(built, seed, kind, opts):
     assert gres.lines() == ores.lines()
     assert np.array_equal(gres.query_off, ores.query_off)
     assert np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32))
-    for f in ("chain_length", "filtered_positions"):
+    for f in ("chain_length", "filtered_positions", "edit_distance", "hpc_len_cur", "hpc_len_ext"):
         assert np.array_equal(gres.recs[f], ores.recs[f])
     assert (gres.query_kmers, gres.seed_hits) == (ores.query_kmers, ores.seed_hits)
     if not opts.get("max_overlaps"):   # with a limit the reference stops visiting groups early
