@@ -1,0 +1,502 @@
+// Chaining stage of getSeqOverlaps for every target group of a batch
+// (reference src/sequence/overlap.cpp:216-458, overlapTest :29-69), in three kernels:
+//
+//   k_group_prep    one wave per group: distinct-position count, span and overhang
+//                   prefilter (:220-262); survivors get their (cur, ext) columns written in
+//                   DP order -- as sorted, or re-sorted by extPos in std::sort order when
+//                   extLen > curLen (:268-275)
+//   k_chain_dp      the chaining DP (:277-323), one wave per group, no LDS: lane L keeps
+//                   element i-1-L in registers (window shifted by one lane per step), the
+//                   reference's look-back scan ("first strictly better j going down, two
+//                   early exits") becomes a wave-wide exclusive prefix max (DPP) + a ballot
+//                   of the exits; look-backs deeper than 64 continue from memory
+//   k_chain_finish  one wave per group: chain starts in descending-score std::sort order
+//                   (:331-334), backtracking with consumption (:338-383), overlapTest,
+//                   primary selection (:431-439, onlyMaxExt)
+#include "fg_wavesort.h"
+
+#include <algorithm>
+
+#define WG 256
+#define I32_MIN ((i32)0x80000000)
+
+struct ChainParams {
+	int k, maxJump, minOverlap, maxOverhang;
+	int checkOverhang, forceLocal;
+	float minUnique;	// minKmerSruvivalRate * _minOverlap as a float (overlap.cpp:110, :235)
+	u32 firstId;
+	int ablate;			// timing experiments only (FG_ABLATE env; results become wrong)
+};
+
+namespace {
+
+struct CandAcc {	// candidates by descending score (overlap.cpp:432-434); w = score
+	typedef int4 T;
+	int4* c;
+	__device__ int4 load(int i) const { return c[i]; }
+	__device__ void store(int i, const int4& x) { c[i] = x; }
+	__device__ bool less(const int4& a, const int4& b) const { return a.w > b.w; }
+};
+
+// overlap.cpp:29-69; the float comparison is evaluated in float exactly as written there
+__device__ __forceinline__ bool overlap_test(const ChainParams& P, u32 curId, u32 extId, i32 curLen,
+											 i32 extLen, i32 cb, i32 ce, i32 eb, i32 ee)
+{
+	const i32 curRange = ce - cb, extRange = ee - eb;
+	if (curRange < P.minOverlap || extRange < P.minOverlap) return false;
+	const float lengthDiff = (float)abs(curRange - extRange);
+	if (lengthDiff > 0.5f * (float)min(curRange, extRange)) return false;
+	if (curId == extId)
+	{
+		const i32 inter = min(ce, ee) - max(cb, eb);
+		if (inter > curRange / 2) return false;
+	}
+	if (curId == (extId ^ 1u))
+	{
+		const i32 inter = min(ce, extLen - eb) - max(cb, extLen - ee);
+		if (inter > curRange / 2) return false;
+	}
+	if (!P.forceLocal && P.checkOverhang)
+	{
+		const i32 ovh = max(min(cb, eb), min(curLen - ce, extLen - ee));
+		if (ovh > P.maxOverhang) return false;
+	}
+	return true;
+}
+
+// ---- lists -------------------------------------------------------------------------------
+// block-aggregated append of the calling thread's group to up to three lists: one atomic
+// per list and 256-thread block (same-address atomics serialise at ~30 ns each)
+__device__ __forceinline__ void append3(bool a, bool b, bool c, u32 g, u32* listA, u32* listB, u32* listC,
+										u32* counts)
+{
+	__shared__ u32 wcnt[3][WG / 64];
+	__shared__ u32 base[3];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const u64 mA = __ballot(a), mB = __ballot(b), mC = __ballot(c);
+	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mA); wcnt[1][wv] = (u32)__popcll(mB); wcnt[2][wv] = (u32)__popcll(mC); }
+	__syncthreads();
+	if (threadIdx.x < 3)
+	{
+		u32 t = 0;
+		for (int i = 0; i < WG / 64; ++i) t += wcnt[threadIdx.x][i];
+		base[threadIdx.x] = t ? atomicAdd(&counts[threadIdx.x], t) : 0u;
+	}
+	__syncthreads();
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+	u32 oA = base[0], oB = base[1], oC = base[2];
+	for (int i = 0; i < wv; ++i) { oA += wcnt[0][i]; oB += wcnt[1][i]; oC += wcnt[2][i]; }
+	if (a) listA[oA + __popcll(mA & below)] = g;
+	if (b) listB[oB + __popcll(mB & below)] = g;
+	if (c) listC[oC + __popcll(mC & below)] = g;
+}
+
+// groups that can still have >= minUnique distinct query positions (unique <= size)
+__global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
+							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primFlag,
+							 u32* __restrict__ dpSize)
+{
+	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
+	u64 n = 0;
+	if (g < nGroups)
+	{
+		primFlag[g] = 0;
+		dpSize[g] = 0;
+		const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+		n = gend - groupStart[g];
+	}
+	append3(n >= minSize && n > 0, false, false, (u32)g, list, list, list, counts);
+}
+
+#define FIN_CAP 256
+// groups that passed the prefilter, all of them (DP) and by size (finish)
+__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listDp,
+						  u32* __restrict__ listSmall, u32* __restrict__ listBig, u32* __restrict__ counts)
+{
+	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
+	const u32 n = g < nGroups ? dpSize[g] : 0u;
+	append3(n > 0, n > 0 && n <= FIN_CAP, n > FIN_CAP, (u32)g, listDp, listSmall, listBig, counts);
+}
+
+// ---- prep --------------------------------------------------------------------------------
+#define PREP_CAP 512
+#define PREP_WAVES 4
+__global__ void __launch_bounds__(PREP_WAVES * 64)
+k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+			 const u32* __restrict__ query, const i32* __restrict__ len,
+			 const u64* __restrict__ hitKey, const u32* __restrict__ hitVal,
+			 u32* __restrict__ gCur, u32* __restrict__ gExt, u32* __restrict__ gAux /* 4 u32 per hit */,
+			 u32* __restrict__ dpSize)
+{
+	__shared__ u32 sExt[PREP_WAVES][PREP_CAP];
+	__shared__ u32 sCur[PREP_WAVES][PREP_CAP];
+	__shared__ unsigned short sPL[PREP_WAVES][PREP_CAP], sPR[PREP_WAVES][PREP_CAP];
+	__shared__ int stack[PREP_WAVES][3 * 40];
+	__shared__ int small[PREP_WAVES][3 * 8];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const u32 li = blockIdx.x * PREP_WAVES + wv;
+	if (li >= nList) return;
+	const u64 g = list[li];
+	const u64 g0 = groupStart[g];
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u64* K = hitKey + g0;
+	const u32* V = hitVal + g0;
+
+	// distinct query positions (overlap.cpp:220-235; prevPos starts at 0) and ext span
+	u32 uniq = 0;
+	i32 minExt = 0x7fffffff, maxExt = I32_MIN;
+	for (i32 i = lane; i < n; i += 64)
+	{
+		const u32 c = (u32)K[i];
+		const u32 pc = i ? (u32)K[i - 1] : 0u;
+		uniq += (c != pc);
+		const i32 e = (i32)V[i];
+		minExt = min(minExt, e); maxExt = max(maxExt, e);
+	}
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		uniq += __shfl_xor(uniq, o);
+		minExt = min(minExt, __shfl_xor(minExt, o));
+		maxExt = max(maxExt, __shfl_xor(maxExt, o));
+	}
+	if ((float)uniq < P.minUnique) return;
+	const u32 qrec = query[groupQuery[g]];
+	const u32 extRec = (u32)(K[0] >> 32) - P.firstId;
+	const i32 curLen = len[qrec >> 1];
+	const i32 extLen = len[extRec >> 1];
+	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
+	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
+	if (P.checkOverhang && !P.forceLocal)
+	{
+		if (min(minCur, minExt) > P.maxOverhang) return;
+		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
+	}
+	if (lane == 0) dpSize[g] = (u32)n;
+
+	u32* oc = gCur + g0;
+	u32* oe = gExt + g0;
+	const bool extSorted = extLen > curLen;
+	if (!extSorted)
+	{
+		for (i32 i = lane; i < n; i += 64) { oc[i] = (u32)K[i]; oe[i] = V[i]; }
+	}
+	else if (n <= PREP_CAP)
+	{
+		for (i32 i = lane; i < n; i += 64) { sCur[wv][i] = (u32)K[i]; sExt[wv][i] = V[i]; }
+		wsort::wave_mem_fence();
+		wsort::wave_sort<u32, unsigned short>(sExt[wv], sCur[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		for (i32 i = lane; i < n; i += 64) { oc[i] = sCur[wv][i]; oe[i] = sExt[wv][i]; }
+	}
+	else
+	{
+		for (i32 i = lane; i < n; i += 64) { oc[i] = (u32)K[i]; oe[i] = V[i]; }
+		wsort::wave_mem_fence();
+		u32* aux = gAux + 4 * g0;
+		wsort::wave_sort<u32, u32>(oe, oc, n, aux, aux + n, stack[wv], small[wv]);
+	}
+}
+
+// ---- DP: one wave per group, no LDS ---------------------------------------------------------
+// lane L <- lane L-1, lane 0 <- fill (DPP wave_shr:1)
+__device__ __forceinline__ i32 wave_shr1(i32 v, i32 fill)
+{
+	return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+// inclusive prefix max over the 64 lanes with DPP row shifts + row broadcasts
+__device__ __forceinline__ i32 wave_incl_max(i32 v)
+{
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x111, 0xf, 0xf, false));	// row_shr:1
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x112, 0xf, 0xf, false));	// row_shr:2
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x114, 0xf, 0xf, false));	// row_shr:4
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x118, 0xf, 0xf, false));	// row_shr:8
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x142, 0xa, 0xf, false));	// row_bcast:15
+	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x143, 0xc, 0xf, false));	// row_bcast:31
+	return v;
+}
+
+// The reference's look-back loop (overlap.cpp:285-316: scan j downwards, keep the first
+// strictly better score, two early exits) runs 64 candidates per step: lane L holds element
+// i-1-L in registers (the window slides one lane per element), an exclusive prefix max in
+// scan order tells every lane whether it would have improved the running best, a ballot of
+// the exit conditions cuts the scan.  The group's columns arrive 64 elements at a time in
+// registers, the results leave the same way; only look-backs deeper than 64 (about 1.6 %
+// of the elements on PacBio-raw data) read memory.
+#define DP_WAVES 4
+__global__ void __launch_bounds__(DP_WAVES * 64)
+k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+		   const u32* __restrict__ query, const i32* __restrict__ len, const u64* __restrict__ hitKey,
+		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
+		   i32* __restrict__ gScore, i32* __restrict__ gBack)
+{
+	const int lane = threadIdx.x & 63;
+	const u32 li = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+	if (li >= nList) return;
+	const u64 g = list[li];
+	const u64 g0 = groupStart[g];
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u32 qrec = query[groupQuery[g]];
+	const u32 extRec = (u32)(hitKey[g0] >> 32) - P.firstId;
+	const bool extSorted = len[extRec >> 1] > len[qrec >> 1];
+	const u32* cur = gCur + g0;
+	const u32* ext = gExt + g0;
+	i32* score = gScore + g0;
+	i32* back = gBack + g0;
+	const int k = P.k;
+	const i32 maxJump = P.maxJump;
+
+	// tile = 64 consecutive elements, one per lane; results of the tile; next tile prefetched
+	i32 tc = lane < n ? (i32)cur[lane] : 0, te = lane < n ? (i32)ext[lane] : 0;
+	i32 ntc = 64 + lane < n ? (i32)cur[64 + lane] : 0, nte = 64 + lane < n ? (i32)ext[64 + lane] : 0;
+	i32 rs = 0, rb = -1;	// element 0: score 0, no predecessor
+	i32 wc = tc, we = te, ws = 0;	// window for i = 1: only lane 0 (element 0) is meaningful
+	for (i32 i = 1; i < n; ++i)
+	{
+		if ((i & 63) == 0)
+		{
+			const i32 tb = i - 64;
+			score[tb + lane] = rs; back[tb + lane] = rb;
+			tc = ntc; te = nte;
+			ntc = i + 64 + lane < n ? (i32)cur[i + 64 + lane] : 0;
+			nte = i + 64 + lane < n ? (i32)ext[i + 64 + lane] : 0;
+		}
+		const int il = __builtin_amdgcn_readfirstlane(i & 63);
+		const i32 cn = __builtin_amdgcn_readlane(tc, il), en = __builtin_amdgcn_readlane(te, il);
+		i32 maxScore = 0, maxId = 0;
+		bool done = false;
+		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
+		{
+			const i32 j = jb - lane;
+			const bool valid = j >= 0;
+			i32 cp = wc, ep = we, sj = ws;
+			if (jb != i - 1)
+			{
+				// deeper than the register window: rare; the scores were stored by this wave
+				__builtin_amdgcn_s_waitcnt(0);
+				cp = 0; ep = 0; sj = 0;
+				if (valid)
+				{
+					cp = (i32)cur[j]; ep = (i32)ext[j];
+					sj = (j >= (i & ~63)) ? 0 : __hip_atomic_load(&score[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				// elements of the current tile are still in registers (rs), not in memory
+				const i32 inTile = __shfl(rs, j & 63);
+				if (valid && j >= (i & ~63)) sj = inTile;
+			}
+			const i32 dc = cn - cp, de = en - ep;
+			const bool inr = valid && dc > 0 && dc < maxJump && de > 0 && de < maxJump;
+			const i32 jd = abs(dc - de);
+			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : I32_MIN;
+			const bool brkB = valid && (extSorted ? de > maxJump : dc > maxJump);
+			const bool brkA = inr && jd == 0 && dc < k;
+			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
+			const bool upd = inr && ns > exc;
+			const u64 stopM = __ballot(brkB || (upd && brkA));
+			const u64 updM = __ballot(upd);
+			const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
+			const u64 um = updM & lim;
+			if (um)
+			{
+				const int lu = 63 - __clzll(um);
+				maxScore = __builtin_amdgcn_readlane(ns, __builtin_amdgcn_readfirstlane(lu));
+				maxId = jb - lu;
+			}
+			if (stopM || ((P.ablate & 1) != 0)) done = true;
+		}
+		const i32 sNew = max(maxScore, k);
+		if (lane == (i & 63)) { rs = sNew; rb = maxScore > k ? maxId : -1; }
+		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
+	}
+	{
+		const i32 tb = (n - 1) & ~63;
+		if (tb + lane < n) { score[tb + lane] = rs; back[tb + lane] = rb; }
+	}
+}
+
+// ---- finish ------------------------------------------------------------------------------
+#define FIN_WAVES 4
+template <bool USE_LDS>
+__global__ void __launch_bounds__(FIN_WAVES * 64)
+k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+			   const u32* __restrict__ query, const i32* __restrict__ len, const u64* __restrict__ hitKey,
+			   const u32* __restrict__ gCur, const u32* __restrict__ gExt, i32* __restrict__ gScore,
+			   i32* __restrict__ gBack, u32* __restrict__ gAux /* 4 u32 per hit */, int4* __restrict__ cand,
+			   const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
+			   PrimRec* __restrict__ prim, u32* __restrict__ primFlag)
+{
+	__shared__ i32 sScore[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ i32 sBack[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ u32 sOKey[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ u32 sOVal[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ unsigned short sPL[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ unsigned short sPR[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	__shared__ int stack[FIN_WAVES][3 * 40];
+	__shared__ int small[FIN_WAVES][3 * 8];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const u32 li = blockIdx.x * FIN_WAVES + wv;
+	if (li >= nList) return;
+	const u64 g = list[li];
+	const u64 g0 = groupStart[g];
+	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u32 q = groupQuery[g];
+	const int k = P.k;
+	const u32* cur = gCur + g0;
+	const u32* ext = gExt + g0;
+	i32 *score, *back; u32 *okey, *oval;
+	if (USE_LDS)
+	{
+		score = sScore[wv]; back = sBack[wv]; okey = sOKey[wv]; oval = sOVal[wv];
+		for (i32 i = lane; i < n; i += 64) { score[i] = gScore[g0 + i]; back[i] = gBack[g0 + i]; }
+		wsort::wave_mem_fence();
+	}
+	else
+	{
+		score = gScore + g0; back = gBack + g0; okey = gAux + 4 * g0; oval = okey + n;
+	}
+	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
+	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
+	wsort::wave_mem_fence();
+	if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+	else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+
+	if (lane != 0) return;
+	// backtracking with consumption, overlapTest, primary selection: one lane
+	const u32 qrec = query[q];
+	const u32 curId = P.firstId + qrec;
+	const u32 extId = (u32)(hitKey[g0] >> 32);
+	const i32 curLen = len[qrec >> 1];
+	const i32 extLen = len[(extId - P.firstId) >> 1];
+	int4* cd = cand + g0;
+	i32 ncand = 0;
+	int4 best = make_int4(0, 0, 0, 0);
+	for (i32 oi = 0; oi < n; ++oi)
+	{
+		const i32 start = (i32)oval[oi];
+		if (back[start] == -1) continue;
+		i32 firstM = 0, chainLength = 0, pos = start;
+		while (pos != -1)
+		{
+			firstM = pos;
+			++chainLength;
+			const i32 np = back[pos];
+			back[pos] = -1;
+			pos = np;
+		}
+		const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
+		const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
+		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
+		const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
+		cd[ncand] = c4;
+		if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
+		++ncand;
+	}
+	if (ncand == 0) return;
+	if (ncand > 16)
+	{
+		CandAcc acc{cd};
+		fgsort::sort(acc, 0, ncand, stack[wv]);	// 3*40 ints >= fgsort::STACK_INTS
+		best = cd[0];
+	}
+	PrimRec r;
+	r.query = q; r.extId = extId;
+	r.curBegin = (i32)cur[best.x]; r.extBegin = (i32)ext[best.x];
+	r.curEnd = (i32)cur[best.y] + k - 1; r.extEnd = (i32)ext[best.y] + k - 1;
+	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
+	{
+		// repetitive query positions inside [curBegin, curEnd] (overlap.cpp:407-413)
+		const i32* fp = filtPos + filtOff[q];
+		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
+		i32 lo = 0, hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
+		const i32 a = lo;
+		hi = nf;
+		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
+		r.filtered = lo - a;
+	}
+	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
+	prim[g] = r;
+	primFlag[g] = 1;
+}
+
+u32 fetchU32(fg_ctx* c, const u32* dptr)
+{
+	u32 v;
+	HIP_CHECK(hipMemcpyAsync(&v, dptr, 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_CHECK(hipStreamSynchronize(c->stream));
+	return v;
+}
+
+} // namespace
+
+// All target groups of the batch -> prim[g] / dPrimFlag[g] / dDpSize[g]
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, PrimRec* prim)
+{
+	hipStream_t s = c->stream;
+	ChainParams cp;
+	cp.k = c->k; cp.maxJump = p->max_jump; cp.minOverlap = p->min_overlap; cp.maxOverhang = p->max_overhang;
+	cp.checkOverhang = p->max_overhang > 0; cp.forceLocal = forceLocal ? 1 : 0;
+	{
+		const float minKmerSruvivalRate = 0.01;	// overlap.cpp:110
+		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
+	}
+	cp.firstId = c->firstId;
+	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
+	if (!nGroups) return;
+	// smallest group size that can still have >= minUnique distinct query positions
+	u32 minSize = 0;
+	while ((float)minSize < cp.minUnique) ++minSize;
+	if (minSize == 0) minSize = 1;
+	c->dListSmall.reserve(nGroups + 1); c->dListBig.reserve(nGroups + 1); c->dListDp.reserve(nGroups + 1);
+	c->dListCnt.reserve(4);
+	c->dCur.reserve(nHits + 16); c->dExt.reserve(nHits + 16);
+	c->dScore.reserve(nHits + 16); c->dBack.reserve(nHits + 16);
+	c->dTmp32.reserve(4 * nHits + 16);
+	c->dCand.reserve(nHits + 1);
+	const unsigned gridG = (unsigned)((nGroups + WG - 1) / WG);
+	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
+	{ ScopedK t(c->timer, "k_group_list");
+	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dListSmall.p,
+						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
+	const u32 nPrep = fetchU32(c, c->dListCnt.p);
+	if (!nPrep) return;
+	{ ScopedK t(c->timer, "k_group_prep");
+	  hipLaunchKernelGGL(k_group_prep, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
+						 nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p,
+						 c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
+	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
+	{ ScopedK t(c->timer, "k_dp_list");
+	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListDp.p, c->dListSmall.p,
+						 c->dListBig.p, c->dListCnt.p); }
+	u32 hc[3];
+	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const u32 nDp = hc[0], nSmall = hc[1], nBig = hc[2];
+	if (!nDp) return;
+	{ ScopedK t(c->timer, "k_chain_dp");
+	  hipLaunchKernelGGL(k_chain_dp, (nDp + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, c->dListDp.p, nDp, nGroups, nHits, c->dGroupStart.p,
+						 c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p,
+						 c->dBack.p); }
+	if (nSmall)
+	{
+		ScopedK t(c->timer, "k_chain_finish<lds>");
+		hipLaunchKernelGGL(k_chain_finish<true>, (nSmall + FIN_WAVES - 1) / FIN_WAVES, FIN_WAVES * 64, 0, s, cp,
+						   c->dListSmall.p, nSmall, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p,
+						   c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p,
+						   c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p);
+	}
+	if (nBig)
+	{
+		ScopedK t(c->timer, "k_chain_finish<global>");
+		hipLaunchKernelGGL(k_chain_finish<false>, (nBig + FIN_WAVES - 1) / FIN_WAVES, FIN_WAVES * 64, 0, s, cp,
+						   c->dListBig.p, nBig, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p,
+						   c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p,
+						   c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p);
+	}
+}

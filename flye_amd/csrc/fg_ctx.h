@@ -176,7 +176,8 @@ struct fg_ctx {
 	DevBuf<u32> dGroupQuery;
 	DevBuf<u32> dTmp32;
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
-	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListCnt;
+	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
+	DevBuf<u32> dCur, dExt;		// (cur, ext) columns of the groups in DP order
 	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
 	DevBuf<char> dSortTasks;
 	DevBuf<int> dEditScratch;
@@ -267,6 +268,7 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, PrimRec* prim);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,

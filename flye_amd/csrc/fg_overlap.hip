@@ -324,312 +324,6 @@ __global__ void k_group_fill(const u64* __restrict__ hitOff, const u64* __restri
 	}
 }
 
-// ---- chaining helpers -------------------------------------------------------------------
-struct ChainParams {
-	int k, maxJump, minOverlap, maxOverhang;
-	int checkOverhang, forceLocal;
-	float minUnique;	// minKmerSruvivalRate * _minOverlap as a float (overlap.cpp:110, :235)
-	u32 firstId;
-	int ablate;			// timing experiments only (FG_ABLATE env, results become wrong)
-};
-
-struct CandAcc {	// candidates by descending score (overlap.cpp:432-434); w = score
-	typedef int4 T;
-	int4* c;
-	__device__ int4 load(int i) const { return c[i]; }
-	__device__ void store(int i, const int4& x) { c[i] = x; }
-	__device__ bool less(const int4& a, const int4& b) const { return a.w > b.w; }
-};
-
-// overlap.cpp:29-69 with the float comparisons in their exact integer form
-// (operands < 2^24)
-__device__ __forceinline__ bool overlap_test(const ChainParams& P, u32 curId, u32 extId, i32 curLen,
-											 i32 extLen, i32 cb, i32 ce, i32 eb, i32 ee)
-{
-	const i32 curRange = ce - cb, extRange = ee - eb;
-	if (curRange < P.minOverlap || extRange < P.minOverlap) return false;
-	const float lengthDiff = (float)abs(curRange - extRange);
-	if (lengthDiff > 0.5f * (float)min(curRange, extRange)) return false;
-	if (curId == extId)
-	{
-		const i32 inter = min(ce, ee) - max(cb, eb);
-		if (inter > curRange / 2) return false;
-	}
-	if (curId == (extId ^ 1u))
-	{
-		const i32 inter = min(ce, extLen - eb) - max(cb, extLen - ee);
-		if (inter > curRange / 2) return false;
-	}
-	if (!P.forceLocal && P.checkOverhang)
-	{
-		const i32 ovh = max(min(cb, eb), min(curLen - ce, extLen - ee));
-		if (ovh > P.maxOverhang) return false;
-	}
-	return true;
-}
-
-// ---- chaining: one wave per target group, group staged in LDS ---------------------------
-// The look-back loop over j (overlap.cpp:285-316) runs 64 candidates per step across the lanes:
-// the reference's "first strictly better j while scanning down, with two early exits"
-// becomes an exclusive prefix-max over the lanes (lane order = scan order), a ballot of
-// the exit conditions and a pick of the last improving lane before the first exit.
-#define I32_MIN ((i32)0x80000000)
-// lane L <- lane L-1, lane 0 <- fill (DPP wave_shr:1)
-__device__ __forceinline__ i32 wave_shr1(i32 v, i32 fill)
-{
-	return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
-}
-// inclusive prefix max over the 64 lanes with DPP row shifts + row broadcasts
-__device__ __forceinline__ i32 wave_incl_max(i32 v)
-{
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x111, 0xf, 0xf, false));	// row_shr:1
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x112, 0xf, 0xf, false));	// row_shr:2
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x114, 0xf, 0xf, false));	// row_shr:4
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x118, 0xf, 0xf, false));	// row_shr:8
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x142, 0xa, 0xf, false));	// row_bcast:15
-	v = max(v, __builtin_amdgcn_update_dpp(I32_MIN, v, 0x143, 0xc, 0xf, false));	// row_bcast:31
-	return v;
-}
-
-#define CHAIN_CAP 256
-#define CHAIN_WAVES 4
-
-template <bool USE_LDS>
-__global__ void __launch_bounds__(CHAIN_WAVES * 64)
-k_chain_wave(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
-			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-			 const u32* __restrict__ query, const i32* __restrict__ len,
-			 u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ gScore,
-			 i32* __restrict__ gBack, u32* __restrict__ gAux /* 5 u32 per hit */,
-			 int4* __restrict__ cand, const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
-			 PrimRec* __restrict__ prim, u32* __restrict__ primFlag, u32* __restrict__ dpSize)
-{
-	__shared__ u32 sCur[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ u32 sExt[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ i32 sScore[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ i32 sBack[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ u32 sOKey[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ u32 sOVal[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ unsigned short sPL[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ unsigned short sPR[USE_LDS ? CHAIN_WAVES : 1][USE_LDS ? CHAIN_CAP : 1];
-	__shared__ int stack[CHAIN_WAVES][3 * 40];
-	__shared__ int small[CHAIN_WAVES][3 * 8];
-	const int wv = threadIdx.x >> 6;
-	const int lane = threadIdx.x & 63;
-	const u32 li = blockIdx.x * CHAIN_WAVES + wv;
-	if (li >= nList) return;
-	const u64 g = list[li];
-	const u64 g0 = groupStart[g];
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
-	const i32 n = (i32)(gend - g0);
-	const u32 q = groupQuery[g];
-	const u64* K = hitKey + g0;
-	const u32* V = hitVal + g0;
-	const int k = P.k;
-
-	u32 *cur, *ext, *okey, *oval; i32 *score, *back;
-	if (USE_LDS)
-	{
-		cur = sCur[wv]; ext = sExt[wv]; score = sScore[wv]; back = sBack[wv]; okey = sOKey[wv]; oval = sOVal[wv];
-	}
-	else
-	{
-		cur = gAux + 5 * g0; okey = cur + n; oval = okey + n;	// + 2n of partition scratch behind oval
-		ext = hitVal + g0; score = gScore + g0; back = gBack + g0;
-	}
-
-	// stage + unique query positions (overlap.cpp:220-235; prevPos starts at 0) + ext range
-	u32 uniq = 0;
-	i32 minExt = 0x7fffffff, maxExt = (i32)0x80000000;
-	for (i32 i = lane; i < n; i += 64)
-	{
-		const u32 c = (u32)K[i];
-		const u32 e = V[i];
-		cur[i] = c;
-		if (USE_LDS) ext[i] = e;
-		const u32 pc = i ? (u32)K[i - 1] : 0u;
-		uniq += (c != pc);
-		minExt = min(minExt, (i32)e); maxExt = max(maxExt, (i32)e);
-	}
-	for (int o = 32; o > 0; o >>= 1)
-	{
-		uniq += __shfl_xor(uniq, o);
-		minExt = min(minExt, __shfl_xor(minExt, o));
-		maxExt = max(maxExt, __shfl_xor(maxExt, o));
-	}
-	if ((float)uniq < P.minUnique) return;
-	const u32 qrec = query[q];
-	const u32 curId = P.firstId + qrec;
-	const u32 extId = (u32)(K[0] >> 32);
-	const u32 extRec = extId - P.firstId;
-	const i32 curLen = len[qrec >> 1];
-	const i32 extLen = len[extRec >> 1];
-	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
-	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
-	if (P.checkOverhang && !P.forceLocal)
-	{
-		if (min(minCur, minExt) > P.maxOverhang) return;
-		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
-	}
-	if (lane == 0) dpSize[g] = (u32)n;
-	wsort::wave_mem_fence();
-
-	const bool extSorted = extLen > curLen;
-	if (extSorted && !(P.ablate & 4))	// overlap.cpp:269-275
-	{
-		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(ext, cur, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
-		else wsort::wave_sort<u32, u32>(ext, cur, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
-	}
-
-	// chaining DP (overlap.cpp:266-323).  Lane L keeps element i-1-L of the scan in
-	// registers (a window sliding by one lane per i), so the usual look-back never
-	// touches memory; older elements come from LDS/global in further 64-wide steps.
-	if (lane == 0) { score[0] = 0; back[0] = -1; }
-	const i32 maxJump = P.maxJump;
-	i32 wc = (i32)cur[0], we = (i32)ext[0], ws = 0;	// only lane 0 is meaningful for i = 1
-	i32 cnNext = n > 1 ? (i32)cur[1] : 0, enNext = n > 1 ? (i32)ext[1] : 0;
-	for (i32 i = 1; i < ((P.ablate & 1) ? 1 : n); ++i)
-	{
-		const i32 cn = cnNext, en = enNext;
-		if (i + 1 < n) { cnNext = (i32)cur[i + 1]; enNext = (i32)ext[i + 1]; }
-		i32 maxScore = 0, maxId = 0;
-		bool done = false;
-		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
-		{
-			const i32 j = jb - lane;
-			const bool valid = j >= 0;
-			i32 cp = wc, ep = we, sj = ws;
-			if (jb != i - 1)
-			{
-				cp = 0; ep = 0; sj = 0;
-				if (valid) { cp = (i32)cur[j]; ep = (i32)ext[j]; sj = score[j]; }
-			}
-			const i32 dc = cn - cp, de = en - ep;
-			const bool inr = valid && dc > 0 && dc < maxJump && de > 0 && de < maxJump;
-			const i32 jd = abs(dc - de);
-			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : I32_MIN;
-			const bool brkB = valid && (extSorted ? de > maxJump : dc > maxJump);
-			const bool brkA = inr && jd == 0 && dc < k;
-			// exclusive prefix max in scan order, seeded with the best of earlier steps
-			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
-			const bool upd = inr && ns > exc;
-			const u64 stopM = __ballot(brkB || (upd && brkA));
-			const u64 updM = __ballot(upd);
-			const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
-			const u64 um = updM & lim;
-			if (um)
-			{
-				const int lu = 63 - __clzll(um);
-				maxScore = __builtin_amdgcn_readlane(ns, __builtin_amdgcn_readfirstlane(lu));
-				maxId = jb - lu;
-			}
-			if (stopM) done = true;
-		}
-		const i32 sNew = max(maxScore, k);
-		if (lane == 0)
-		{
-			score[i] = sNew;
-			back[i] = maxScore > k ? maxId : -1;
-		}
-		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
-	}
-	wsort::wave_mem_fence();
-
-	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
-	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
-	wsort::wave_mem_fence();
-	if (!(P.ablate & 2))
-	{
-		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
-		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
-	}
-
-	if (lane != 0 || (P.ablate & 8)) return;
-	// backtrack, overlapTest, primary selection: short pointer chases, one lane
-	int4* cd = cand + g0;
-	i32 ncand = 0;
-	int4 best = make_int4(0, 0, 0, 0);
-	for (i32 oi = 0; oi < n; ++oi)
-	{
-		const i32 start = (i32)oval[oi];
-		if (back[start] == -1) continue;
-		i32 firstM = 0, chainLength = 0, pos = start;
-		while (pos != -1)
-		{
-			firstM = pos;
-			++chainLength;
-			const i32 np = back[pos];
-			back[pos] = -1;
-			pos = np;
-		}
-		const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
-		const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
-		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
-		const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
-		cd[ncand] = c4;
-		if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
-		++ncand;
-	}
-	if (ncand == 0) return;
-	if (ncand > 16)
-	{
-		CandAcc acc{cd};
-		fgsort::sort(acc, 0, ncand, stack[wv]);	// 3*40 ints >= fgsort::STACK_INTS
-		best = cd[0];
-	}
-	PrimRec r;
-	r.query = q; r.extId = extId;
-	r.curBegin = (i32)cur[best.x]; r.extBegin = (i32)ext[best.x];
-	r.curEnd = (i32)cur[best.y] + k - 1; r.extEnd = (i32)ext[best.y] + k - 1;
-	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
-	{
-		const i32* fp = filtPos + filtOff[q];
-		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
-		i32 lo = 0, hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
-		const i32 a = lo;
-		hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
-		r.filtered = lo - a;
-	}
-	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
-	prim[g] = r;
-	primFlag[g] = 1;
-}
-
-// size classes for the chaining kernels; groups that cannot reach the minimum number
-// of distinct query positions are dropped here (unique <= size)
-__global__ void k_group_classify(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
-								 u32* __restrict__ listSmall, u32* __restrict__ listBig,
-								 u32* __restrict__ counts /* [0] small, [1] big */, u32* __restrict__ primFlag,
-								 u32* __restrict__ dpSize)
-{
-	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	u64 n = 0;
-	if (g < nGroups)
-	{
-		primFlag[g] = 0;
-		dpSize[g] = 0;
-		const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
-		n = gend - groupStart[g];
-	}
-	const bool small = n >= minSize && n <= CHAIN_CAP;
-	const bool big = n > CHAIN_CAP && n >= minSize;
-	// one atomic per wave and list
-	const u64 mS = __ballot(small), mB = __ballot(big);
-	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	u32 baseS = 0, baseB = 0;
-	if (lane == 0)
-	{
-		if (mS) baseS = atomicAdd(&counts[0], (u32)__popcll(mS));
-		if (mB) baseB = atomicAdd(&counts[1], (u32)__popcll(mB));
-	}
-	baseS = __shfl(baseS, 0); baseB = __shfl(baseB, 0);
-	if (small) listSmall[baseS + __popcll(mS & below)] = (u32)g;
-	if (big) listBig[baseB + __popcll(mB & below)] = (u32)g;
-}
-
 __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
 							 const u32* __restrict__ dpSize, u64* __restrict__ primCnt,
 							 u64* __restrict__ dpGroups, u64* __restrict__ dpElems)
@@ -793,63 +487,18 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
 	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "batch too large: split the query list"};
 	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
-	c->dCand.reserve(nHits + 1);
 	c->dPrim.reserve((nGroups + 1) * sizeof(PrimRec));
 	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
-	c->dListSmall.reserve(nGroups + 1); c->dListBig.reserve(nGroups + 1);
 	PrimRec* prim = (PrimRec*)c->dPrim.p;
 	{ ScopedK t(c->timer, "k_group_fill");
 	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
 						 c->dGroupQuery.p); }
-	ChainParams cp;
-	cp.k = k; cp.maxJump = p->max_jump; cp.minOverlap = p->min_overlap; cp.maxOverhang = p->max_overhang;
-	cp.checkOverhang = p->max_overhang > 0; cp.forceLocal = forceLocal ? 1 : 0;
+	if (getenv("FG_ABLATE"))
 	{
-		const float minKmerSruvivalRate = 0.01;	// overlap.cpp:110
-		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
+		const int ab = atoi(getenv("FG_ABLATE"));
+		HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(wsort::g_ablate), &ab, sizeof(int)));
 	}
-	cp.firstId = c->firstId;
-	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
-	{
-		static int lastAblate = 0;
-		if (cp.ablate != lastAblate)
-		{
-			HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(wsort::g_ablate), &cp.ablate, sizeof(int)));
-			lastAblate = cp.ablate;
-		}
-	}
-	if (nGroups)
-	{
-		// smallest group size that can still have >= minUnique distinct query positions
-		u32 minSize = 0;
-		while ((float)minSize < cp.minUnique) ++minSize;
-		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
-		{ ScopedK t(c->timer, "k_group_classify");
-		  hipLaunchKernelGGL(k_group_classify, (unsigned)((nGroups + WG - 1) / WG), WG, 0, s, nGroups, nHits,
-							 c->dGroupStart.p, minSize, c->dListSmall.p, c->dListBig.p, c->dListCnt.p,
-							 c->dPrimFlag.p, c->dDpSize.p); }
-		u32 hc[2];
-		HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipStreamSynchronize(s));
-		if (hc[0])
-		{
-			ScopedK t(c->timer, "k_chain_wave<lds>");
-			hipLaunchKernelGGL(k_chain_wave<true>, (hc[0] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
-							   cp, c->dListSmall.p, hc[0], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
-							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, (i32*)nullptr, (i32*)nullptr, (u32*)nullptr,
-							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p, c->dDpSize.p);
-		}
-		if (hc[1])
-		{
-			c->dTmp32.reserve(5 * nHits + 5);
-			c->dScore.reserve(nHits + 1); c->dBack.reserve(nHits + 1);
-			ScopedK t(c->timer, "k_chain_wave<global>");
-			hipLaunchKernelGGL(k_chain_wave<false>, (hc[1] + CHAIN_WAVES - 1) / CHAIN_WAVES, CHAIN_WAVES * 64, 0, s,
-							   cp, c->dListBig.p, hc[1], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p,
-							   c->dLen.p, c->dHitKey.p, c->dHitVal.p, c->dScore.p, c->dBack.p, c->dTmp32.p,
-							   c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p, c->dDpSize.p);
-		}
-	}
+	fgChainStage(c, p, forceLocal, nGroups, nHits, prim);
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
 						 c->dDpGroups.p, c->dDpElems.p); }

@@ -650,8 +650,10 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 		{
 			int32_t maxScore = 0, maxId = 0;
 			const int32_t curNext = M[i].cur, extNext = M[i].ext;
+			int32_t scanned = 0;
 			for (int32_t j = i - 1; j >= 0; --j)
 			{
+				++scanned;
 				const int32_t curPrev = M[j].cur, extPrev = M[j].ext;
 				if (0 < curNext - curPrev && curNext - curPrev < P.max_jump &&
 					0 < extNext - extPrev && extNext - extPrev < P.max_jump)
@@ -670,6 +672,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 				if (extSorted && extNext - extPrev > P.max_jump) break;
 				if (!extSorted && curNext - curPrev > P.max_jump) break;
 			}
+			counters[4] += scanned; counters[5] += scanned > 16; counters[6] += scanned > 64;
 			S.score[i] = std::max(maxScore, k);
 			if (maxScore > k) S.back[i] = maxId;
 		}
@@ -776,7 +779,7 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 	std::vector<std::vector<float>> st(nq);
 	int T = std::max(1, threads);
 	std::vector<Scratch> scratch(T);
-	std::vector<std::array<u64, 4>> cnt(T, std::array<u64, 4>{0, 0, 0, 0});
+	std::vector<std::array<u64, 8>> cnt(T, std::array<u64, 8>{0, 0, 0, 0, 0, 0, 0, 0});
 	for (u32 i = 0; i < nq; ++i)
 		if (queryIds[i] < c.firstId || queryIds[i] - c.firstId >= 2 * c.n) return FG_ERR_ARG;
 	parallelFor(nq, T, [&](u32 i, int t)
@@ -796,6 +799,13 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 	c.outOff[nq] = c.outRecs.size(); c.statOff[nq] = c.outStats.size();
 	c.cntKmers = c.cntHits = c.cntGroups = c.cntDp = 0;
 	for (auto& a : cnt) { c.cntKmers += a[0]; c.cntHits += a[1]; c.cntGroups += a[2]; c.cntDp += a[3]; }
+	if (getenv("FO_STATS"))
+	{
+		u64 st[3] = {0, 0, 0};
+		for (auto& a : cnt) { st[0] += a[4]; st[1] += a[5]; st[2] += a[6]; }
+		fprintf(stderr, "look-back: %.2f candidates scanned per DP element; %.2f%% of elements scan > 16, %.2f%% > 64\n",
+				(double)st[0] / std::max<u64>(1, c.cntDp), 100.0 * st[1] / std::max<u64>(1, c.cntDp), 100.0 * st[2] / std::max<u64>(1, c.cntDp));
+	}
 	*nRecs = c.outRecs.size(); *nStats = c.outStats.size();
 	return 0;
 }

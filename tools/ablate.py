@@ -12,4 +12,4 @@ for ab in [int(x) for x in (sys.argv[1:] or ['0','1','2','4','8','15','0'])]:
     os.environ["FG_ABLATE"] = str(ab)
     r = det.getSeqOverlapsBatch(q)
     kt = ctx.kernel_times()
-    print("ablate", ab, "dp_groups", r.dp_groups, "dp_el", r.dp_elements, {k: round(v[0]*1e3, 2) for k, v in kt.items() if "chain" in k or "sort" in k}, flush=True)
+    print("ablate", ab, "dp_groups", r.dp_groups, "dp_el", r.dp_elements, {k: round(v[0]*1e3, 2) for k, v in kt.items() if "chain" in k or "sort" in k or "group" in k or "dp_list" in k}, flush=True)
