@@ -130,7 +130,7 @@ def main():
         d = res.dp_elements / max(1, res.query_bp)
         ovl = len(res.recs) / max(1, res.query_bp)
         # dominant kernel of the timed region (HIP events on the library stream)
-        dom = max(ktimes.items(), key=lambda kv: kv[1][0])
+        dom = max(((k_, v_) for k_, v_ in ktimes.items() if not k_.startswith("host:")), key=lambda kv: kv[1][0])
         dom_name, (dom_sec, dom_n) = dom
         launches_per_step = max(1, dom_n // args.steps)
         avg_launch_s = dom_sec / max(1, dom_n)

@@ -6,6 +6,28 @@
 #include <algorithm>
 #include <new>
 
+#include <mutex>
+
+static std::mutex g_poolMutex;
+static std::vector<BatchOwner*> g_pool;
+
+BatchOwner* BatchOwner::acquire()
+{
+	std::lock_guard<std::mutex> lock(g_poolMutex);
+	if (g_pool.empty()) return new BatchOwner;
+	BatchOwner* b = g_pool.back();
+	g_pool.pop_back();
+	return b;
+}
+
+void BatchOwner::release(BatchOwner* b)
+{
+	if (!b) return;
+	std::lock_guard<std::mutex> lock(g_poolMutex);
+	if (g_pool.size() < 2) { b->nRecs = 0; b->stats.clear(); g_pool.push_back(b); }
+	else delete b;
+}
+
 namespace {
 
 template <class F>
@@ -181,11 +203,17 @@ int fg_overlaps(fg_ctx* c, const struct fg_detector_params* p, const uint32_t* q
 	if (p->max_jump <= 0 || p->min_overlap <= 0 || max_overlaps < 0) return FG_ERR_ARG;
 	for (u32 i = 0; i < n_queries; ++i)
 		if (query_ids[i] < c->firstId || query_ids[i] - c->firstId >= 2 * c->nReads) return FG_ERR_ARG;
-	return guarded(c, [&]()
+	const int rc = guarded(c, [&]()
 	{
 		HIP_CHECK(hipSetDevice(c->device));
 		fgOverlaps(c, p, query_ids, n_queries, max_overlaps, force_local, out);
 	});
+	if (rc != FG_OK)
+	{
+		BatchOwner::release((BatchOwner*)out->owner_);
+		memset(out, 0, sizeof(*out));
+	}
+	return rc;
 }
 
 int fg_debug_sort_pairs(fg_ctx* c, uint64_t* keys, uint32_t* vals, const uint64_t* seg_off, uint32_t n_seg)
@@ -201,7 +229,7 @@ int fg_debug_sort_pairs(fg_ctx* c, uint64_t* keys, uint32_t* vals, const uint64_
 void fg_release_batch(struct fg_overlap_batch* b)
 {
 	if (!b) return;
-	delete (BatchOwner*)b->owner_;
+	BatchOwner::release((BatchOwner*)b->owner_);
 	memset(b, 0, sizeof(*b));
 }
 

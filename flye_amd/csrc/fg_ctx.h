@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <new>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -250,10 +252,25 @@ __device__ __forceinline__ u64 fg_probe(const ulonglong2* __restrict__ table, u6
 
 #endif // __HIPCC__
 
+// result arena of one fg_overlaps call.  recs is a raw grow-only buffer (no value
+// initialisation of ~100 MB per call); released arenas go back to a small per-process pool
+// so that steady-state calls neither page-fault nor munmap.
 struct BatchOwner {
 	std::vector<u64> queryOff, statOff;
-	std::vector<fg_overlap_rec> recs;
+	fg_overlap_rec* recs = nullptr;
+	size_t recCap = 0, nRecs = 0;
 	std::vector<float> stats;
+	void reserveRecs(size_t n)
+	{
+		if (n <= recCap) return;
+		free(recs);
+		recCap = n + n / 8 + 16;
+		recs = (fg_overlap_rec*)malloc(recCap * sizeof(fg_overlap_rec));
+		if (!recs) { recCap = 0; throw std::bad_alloc(); }
+	}
+	~BatchOwner() { free(recs); }
+	static BatchOwner* acquire();
+	static void release(BatchOwner* b);
 };
 
 // one primary overlap candidate as the device hands it to the host shim

@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -409,11 +410,12 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	c->timer.evs.clear();
+	const auto tHost0 = std::chrono::steady_clock::now();
 	hipEvent_t evA, evB;
 	HIP_CHECK(hipEventCreate(&evA)); HIP_CHECK(hipEventCreate(&evB));
 	HIP_CHECK(hipEventRecord(evA, s));
 
-	BatchOwner* own = new BatchOwner;
+	BatchOwner* own = BatchOwner::acquire();
 	out->owner_ = own;
 	out->n_queries = nq;
 	own->queryOff.assign(nq + 1, 0);
@@ -525,6 +527,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	HIP_CHECK(hipStreamSynchronize(s));
 	out->dp_groups = 0; out->dp_elements = 0;
 	for (u32 i = 0; i < nq; ++i) { out->dp_groups += hDpG[i]; out->dp_elements += hDpE[i]; }
+	const auto tHost1 = std::chrono::steady_clock::now();
 
 	// ---- host shim: floats with the host libm, the gate, prefix rule, window stats ----
 	// two passes over the queries, both fanned out over host threads: (1) divergence,
@@ -590,7 +593,9 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		own->queryOff[qi + 1] += own->queryOff[qi];
 		own->statOff[qi + 1] = own->statOff[qi] + nStat[qi];
 	}
-	own->recs.resize(own->queryOff[nq]);
+	own->reserveRecs(own->queryOff[nq]);
+	own->nRecs = own->queryOff[nq];
+	own->stats.clear();
 	own->stats.reserve(own->statOff[nq]);
 	for (unsigned t = 0; t < nThreads; ++t) own->stats.insert(own->stats.end(), statVals[t].begin(), statVals[t].end());
 	auto pass2 = [&](unsigned t)
@@ -599,7 +604,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		for (u32 qi = q0; qi < q1; ++qi)
 		{
 			const i32 curLen = c->hLen[hq[qi] >> 1];
-			fg_overlap_rec* dst = own->recs.data() + own->queryOff[qi];
+			fg_overlap_rec* dst = own->recs + own->queryOff[qi];
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
 				if (!keep[j]) continue;
@@ -616,9 +621,9 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		}
 	};
 	runThreads(pass2);
-	out->n_recs = own->recs.size();
+	out->n_recs = own->nRecs;
 	out->query_off = own->queryOff.data();
-	out->recs = own->recs.data();
+	out->recs = own->recs;
 	out->n_div_stats = own->stats.size();
 	out->div_stats_off = own->statOff.data();
 	out->div_stats = own->stats.data();
@@ -627,4 +632,9 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	out->device_seconds = ms * 1e-3;
 	HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 	c->timer.collect();
+	const auto tHost2 = std::chrono::steady_clock::now();
+	c->timer.last.push_back(fg_kernel_time{"host:launch+sync (wall, includes the device time)",
+							std::chrono::duration<double>(tHost1 - tHost0).count(), 1});
+	c->timer.last.push_back(fg_kernel_time{"host:shim (divergence, gate, records)",
+							std::chrono::duration<double>(tHost2 - tHost1).count(), 1});
 }
