@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scale", type=float, default=None, help="genome scale (default = --gpus)")
-    ap.add_argument("--cpu-sample-bp", type=float, default=25e6)
+    ap.add_argument("--cpu-sample-bp", type=float, default=250e6)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -68,11 +68,20 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # rehearsal on a one-GPU box: FLYE_BENCH_BACKEND=gloo puts every rank on the visible GPUs
+    # round-robin and reduces through CPU tensors (RCCL refuses two ranks on one device)
+    backend = os.environ.get("FLYE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     import torch.distributed as td
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from flye_amd import config, dist, gpu, workloads
 
@@ -116,8 +125,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    bp = torch.tensor([my_bp], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    bp = torch.tensor([my_bp], dtype=torch.float64, device=red_dev)
     if world > 1:
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         td.all_reduce(bp, op=td.ReduceOp.SUM)

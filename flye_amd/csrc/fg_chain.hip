@@ -287,11 +287,15 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 				const i32 inTile = __shfl(rs, j & 63);
 				if (valid && j >= (i & ~63)) sj = inTile;
 			}
+			// straight-line (no exec-mask branches): unsigned range tests, selects
 			const i32 dc = cn - cp, de = en - ep;
-			const bool inr = valid && dc > 0 && dc < maxJump && de > 0 && de < maxJump;
+			const bool inr = valid && (u32)(dc - 1) < (u32)(maxJump - 1) && (u32)(de - 1) < (u32)(maxJump - 1);
 			const i32 jd = abs(dc - de);
-			const i32 ns = inr ? sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1)) : I32_MIN;
-			const bool brkB = valid && (extSorted ? de > maxJump : dc > maxJump);
+			i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
+			asm volatile("" : "+v"(nsRaw));	// keep the arithmetic out of a conditional block
+			const i32 ns = inr ? nsRaw : I32_MIN;
+			const i32 gapSel = extSorted ? de : dc;
+			const bool brkB = valid && gapSel > maxJump;
 			const bool brkA = inr && jd == 0 && dc < k;
 			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
 			const bool upd = inr && ns > exc;

@@ -142,7 +142,10 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 }
 
 // expand every hit list in query order (overlap.cpp:176-196); a stored entry
-// (record, pos) is reported in the query k-mer's orientation (vertex_index.h:158-174)
+// (record, pos) is reported in the query k-mer's orientation (vertex_index.h:158-174).
+// Per 256 query positions: owners publish (output start, list offset, count, flags) in
+// LDS, then the block walks the OUTPUT slots -- thread o finds its owner by bisection of the
+// starts -- so the 12-byte hit records leave as coalesced stores.
 __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len,
 					   const u64* __restrict__ qKmerOff, int k, u32 firstId,
 					   const u64* __restrict__ probe, const u64* __restrict__ entries,
@@ -150,41 +153,61 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 					   u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ filtPos)
 {
 	__shared__ u32 sh[WG / 64 + 1];
+	__shared__ u32 sStart[WG + 1];
+	__shared__ u64 sOff[WG];
+	__shared__ u32 sSelf[WG];	// index of the trivial self hit inside the list, or 0xFFFFFFFF
 	const u32 q = blockIdx.x;
 	const u32 rec = query[q];
-	const i32 nk = len[rec >> 1] - k;
+	const i32 L = len[rec >> 1];
+	const i32 nk = L - k;
 	const u64* pr = probe + qKmerOff[q];
 	u64 hbase = hitOff[q];
 	u64 fbase = filtOff[q];
 	for (i32 p0 = 0; p0 < nk; p0 += WG)
 	{
 		const i32 p = p0 + threadIdx.x;
-		u64 v = p < nk ? pr[p] : 0;
+		const u64 v = p < nk ? pr[p] : 0;
 		u32 cnt = (u32)(v & FG_CNT_MASK);
 		const bool rep = (cnt == FG_CNT_REPETITIVE);
 		if (rep) cnt = 0;
-		const u32 self = (v & FLAG_SELF) ? 1u : 0u;
+		const bool flip = v & FLAG_FLIP;
+		const u64 off = (v >> FG_CNT_BITS) & OFF_MASK;
+		u32 selfIdx = 0xFFFFFFFFu;
+		if (cnt && (v & FLAG_SELF))
+		{
+			// the list is ascending: find this position's own entry (it exists)
+			const u64 own = ((u64)(rec ^ (flip ? 1u : 0u)) << 32) | (u32)(flip ? L - p - k : p);
+			u32 lo = 0, hi = cnt;
+			while (lo < hi) { const u32 m = (lo + hi) >> 1; if (entries[off + m] < own) lo = m + 1; else hi = m; }
+			selfIdx = lo;
+		}
+		const u32 eff = cnt - (selfIdx != 0xFFFFFFFFu ? 1u : 0u);
 		u32 tot, ftot;
-		const u32 start = block_exscan(cnt - (cnt ? self : 0), sh, &tot);
+		const u32 start = block_exscan(eff, sh, &tot);
 		const u32 fstart = block_exscan(rep ? 1u : 0u, sh, &ftot);
 		if (rep) filtPos[fbase + fstart] = p;
-		if (cnt)
+		sStart[threadIdx.x] = start;
+		sOff[threadIdx.x] = off | (flip ? FLAG_FLIP : 0ULL);
+		sSelf[threadIdx.x] = selfIdx;
+		if (threadIdx.x == 0) sStart[WG] = tot;
+		__syncthreads();
+		for (u32 o = threadIdx.x; o < tot; o += WG)
 		{
-			const bool flip = v & FLAG_FLIP;
-			const u64 off = (v >> FG_CNT_BITS) & OFF_MASK;
-			u64 o = hbase + start;
-			for (u32 j = 0; j < cnt; ++j)
-			{
-				const u64 e = entries[off + j];
-				u32 srec = (u32)(e >> 32);
-				i32 spos = (i32)(u32)e;
-				if (flip) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
-				if (srec == rec && spos == p) continue;	// no trivial matches (overlap.cpp:188-190)
-				hitKey[o] = ((u64)(firstId + srec) << 32) | (u32)p;
-				hitVal[o] = (u32)spos;
-				++o;
-			}
+			// owner = last t with sStart[t] <= o (it has a non-empty list)
+			u32 lo = 0, hi = WG;
+			while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (sStart[m] <= o) lo = m; else hi = m; }
+			const u32 t = lo;
+			u32 j = o - sStart[t];
+			if (j >= sSelf[t]) ++j;	// no trivial matches (overlap.cpp:188-190)
+			const u64 so = sOff[t];
+			const u64 e = entries[(so & OFF_MASK) + j];
+			u32 srec = (u32)(e >> 32);
+			i32 spos = (i32)(u32)e;
+			if (so & FLAG_FLIP) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
+			hitKey[hbase + o] = ((u64)(firstId + srec) << 32) | (u32)(p0 + (i32)t);
+			hitVal[hbase + o] = (u32)spos;
 		}
+		__syncthreads();
 		hbase += tot;
 		fbase += ftot;
 	}
