@@ -367,10 +367,13 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
 	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
 	wsort::wave_mem_fence();
-	if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
-	else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+	if (!(P.ablate & 2))
+	{
+		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+	}
 
-	if (lane != 0) return;
+	if (lane != 0 || (P.ablate & 8)) return;
 	// backtracking with consumption, overlapTest, primary selection: one lane
 	const u32 qrec = query[q];
 	const u32 curId = P.firstId + qrec;

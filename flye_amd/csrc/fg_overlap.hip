@@ -427,6 +427,101 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 	HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// Device part of one chunk of queries [qa, qb): seed collection -> sort -> groups ->
+// chaining -> (edit distance) -> compacted primaries in c->hPrim / offsets in c->hOff.
+// Returns false (nothing done) when the chunk's hits exceed the budget and it can be split.
+struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems; };
+
+static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, const u32* hq,
+						const u64* hQKmerOff, u32 qa, u32 qb, u64 hitBudget, ChunkResult* res)
+{
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 nq = qb - qa;
+	const u64 totalQK = hQKmerOff[qb] - hQKmerOff[qa];
+	std::vector<u64> localOff(nq + 1);
+	for (u32 i = 0; i <= nq; ++i) localOff[i] = hQKmerOff[qa + i] - hQKmerOff[qa];
+	c->dQuery.reserve(nq); c->dQKmerOff.reserve(nq + 1);
+	c->dProbe.reserve(totalQK);
+	c->dHitOff.reserve(nq + 1); c->dFiltOff.reserve(nq + 1);
+	c->dCntA.reserve(nq + 1); c->dCntB.reserve(nq + 1); c->dGroupCnt.reserve(nq + 1); c->dGroupOff.reserve(nq + 1);
+	c->dPrimCnt.reserve(nq + 1); c->dPrimOff.reserve(nq + 1); c->dDpGroups.reserve(nq + 1); c->dDpElems.reserve(nq + 1);
+	c->dListCnt.reserve(4);
+	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, hq + qa, nq * 4ULL, hipMemcpyHostToDevice, s));
+	HIP_CHECK(hipMemcpyAsync(c->dQKmerOff.p, localOff.data(), (nq + 1) * 8ULL, hipMemcpyHostToDevice, s));
+
+	{ ScopedK t(c->timer, "k_probe");
+	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p,
+						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->dIndexedBits.p, c->dProbe.p,
+						 c->dCntA.p, c->dCntB.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }
+	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
+	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
+	if (nHits > hitBudget && nq > 1) return false;
+	res->nHits = nHits;
+	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
+	{ ScopedK t(c->timer, "k_fill");
+	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
+						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
+	{
+		const u64 cap64 = nHits / 8 + 4ULL * nq + 1024;
+		const u32 taskCap = (u32)std::min<u64>(cap64, 0x7fffffffULL);
+		c->dTmp32.reserve(2 * nHits + 2);
+		c->dSortTasks.reserve((size_t)taskCap * sizeof(SortTask));
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
+		{ ScopedK t(c->timer, "k_sort_top");
+		  hipLaunchKernelGGL(k_sort_top, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
+							 c->dHitVal.p, nq, c->dTmp32.p, nHits, (SortTask*)c->dSortTasks.p, taskCap, c->dListCnt.p); }
+		u32 nTasks = fetchScalar(c, c->dListCnt.p);
+		nTasks = std::min(nTasks, taskCap);
+		if (nTasks)
+		{
+			ScopedK t(c->timer, "k_sort_lds");
+			hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+							   (const SortTask*)c->dSortTasks.p, c->dListCnt.p, taskCap, c->dHitKey.p, c->dHitVal.p);
+		}
+	}
+	{ ScopedK t(c->timer, "k_group_count");
+	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
+	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
+	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "too many target groups in one chunk"};
+	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
+	c->dPrim.reserve((nGroups + 1) * sizeof(PrimRec));
+	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
+	PrimRec* prim = (PrimRec*)c->dPrim.p;
+	{ ScopedK t(c->timer, "k_group_fill");
+	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
+						 c->dGroupQuery.p); }
+	fgChainStage(c, p, forceLocal, nGroups, nHits, prim);
+	{ ScopedK t(c->timer, "k_prim_count");
+	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
+						 c->dDpGroups.p, c->dDpElems.p); }
+	{ ScopedK t(c->timer, "k_exscan");
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dPrimCnt.p, c->dPrimOff.p, nq); }
+	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
+	c->dPrimOut.reserve((nPrim + 1) * sizeof(PrimRec));
+	{ ScopedK t(c->timer, "k_prim_gather");
+	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, prim, c->dPrimOff.p,
+						 (PrimRec*)c->dPrimOut.p); }
+	if (p->nucl_alignment) fgEditDistances(c, (PrimRec*)c->dPrimOut.p, nPrim, p->use_hpc);
+	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
+	c->hOff.reserve(3 * (size_t)(nq + 1));
+	{ ScopedK t(c->timer, "copy_results_d2h");
+	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p, c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s)); }
+	HIP_CHECK(hipStreamSynchronize(s));
+	res->nPrim = nPrim;
+	res->dpGroups = 0; res->dpElems = 0;
+	for (u32 i = 0; i < nq; ++i) { res->dpGroups += c->hOff.p[(nq + 1) + i]; res->dpElems += c->hOff.p[2 * (size_t)(nq + 1) + i]; }
+	return true;
+}
+
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out)
 {
@@ -455,101 +550,71 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		hQKmerOff[i + 1] = hQKmerOff[i] + (u64)std::max(0, L - k);
 		queryBp += L;
 	}
-	const u64 totalQK = hQKmerOff[nq];
 	out->query_bp = queryBp;
-	out->query_kmers = totalQK;
+	out->query_kmers = hQKmerOff[nq];
 	if (nq == 0)
 	{
 		out->query_off = own->queryOff.data(); out->div_stats_off = own->statOff.data();
 		HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 		return;
 	}
-	c->dQuery.reserve(nq); c->dQKmerOff.reserve(nq + 1);
-	c->dProbe.reserve(totalQK);
-	c->dHitOff.reserve(nq + 1); c->dFiltOff.reserve(nq + 1);
-	c->dCntA.reserve(nq + 1); c->dCntB.reserve(nq + 1); c->dGroupCnt.reserve(nq + 1); c->dGroupOff.reserve(nq + 1);
-	c->dPrimCnt.reserve(nq + 1); c->dPrimOff.reserve(nq + 1); c->dDpGroups.reserve(nq + 1); c->dDpElems.reserve(nq + 1);
-	c->dListCnt.reserve(2);
-	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, hq.data(), nq * 4ULL, hipMemcpyHostToDevice, s));
-	HIP_CHECK(hipMemcpyAsync(c->dQKmerOff.p, hQKmerOff.data(), (nq + 1) * 8ULL, hipMemcpyHostToDevice, s));
-
-	{ ScopedK t(c->timer, "k_probe");
-	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p,
-						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->dIndexedBits.p, c->dProbe.p,
-						 c->dCntA.p, c->dCntB.p); }
-	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }
-	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
-	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
-	out->seed_hits = nHits;
-	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
-	{ ScopedK t(c->timer, "k_fill");
-	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
-						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
-	{
-		const u64 cap64 = nHits / 8 + 4ULL * nq + 1024;
-		const u32 taskCap = (u32)std::min<u64>(cap64, 0x7fffffffULL);
-		c->dTmp32.reserve(2 * nHits + 2);
-		c->dSortTasks.reserve((size_t)taskCap * sizeof(SortTask));
-		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
-		{ ScopedK t(c->timer, "k_sort_top");
-		  hipLaunchKernelGGL(k_sort_top, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
-							 c->dHitVal.p, nq, c->dTmp32.p, nHits, (SortTask*)c->dSortTasks.p, taskCap, c->dListCnt.p); }
-		u32 nTasks = fetchScalar(c, c->dListCnt.p);
-		nTasks = std::min(nTasks, taskCap);
-		if (nTasks)
-		{
-			ScopedK t(c->timer, "k_sort_lds");
-			hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-							   (const SortTask*)c->dSortTasks.p, c->dListCnt.p, taskCap, c->dHitKey.p, c->dHitVal.p);
-		}
-	}
-	{ ScopedK t(c->timer, "k_group_count");
-	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
-	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
-	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
-	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "batch too large: split the query list"};
-	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
-	c->dPrim.reserve((nGroups + 1) * sizeof(PrimRec));
-	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
-	PrimRec* prim = (PrimRec*)c->dPrim.p;
-	{ ScopedK t(c->timer, "k_group_fill");
-	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
-						 c->dGroupQuery.p); }
 	if (getenv("FG_ABLATE"))
 	{
 		const int ab = atoi(getenv("FG_ABLATE"));
 		HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(wsort::g_ablate), &ab, sizeof(int)));
 	}
-	fgChainStage(c, p, forceLocal, nGroups, nHits, prim);
-	{ ScopedK t(c->timer, "k_prim_count");
-	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
-						 c->dDpGroups.p, c->dDpElems.p); }
-	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dPrimCnt.p, c->dPrimOff.p, nq); }
-	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
-	c->dPrimOut.reserve((nPrim + 1) * sizeof(PrimRec));
-	{ ScopedK t(c->timer, "k_prim_gather");
-	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, prim, c->dPrimOff.p,
-						 (PrimRec*)c->dPrimOut.p); }
-	if (p->nucl_alignment) fgEditDistances(c, (PrimRec*)c->dPrimOut.p, nPrim, p->use_hpc);
-	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
-	c->hOff.reserve(3 * (size_t)(nq + 1));
-	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
-	const u64* hPrimOff = c->hOff.p;
-	const u64* hDpG = c->hOff.p + (nq + 1);
-	const u64* hDpE = c->hOff.p + 2 * (size_t)(nq + 1);
-	{ ScopedK t(c->timer, "copy_results_d2h");
-	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p, c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
-	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
-	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
-	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s)); }
+
+	// The batch is cut into chunks so that the per-chunk scratch (8 B per query k-mer,
+	// ~70 B per seed hit) stays bounded whatever the caller passes; a chunk whose hits
+	// exceed the budget is halved.  E. coli 50x is one chunk.
+	const u64 kmerBudget = getenv("FG_KMER_BUDGET") ? strtoull(getenv("FG_KMER_BUDGET"), nullptr, 10) : (1ULL << 30);
+	const u64 hitBudget = getenv("FG_HIT_BUDGET") ? strtoull(getenv("FG_HIT_BUDGET"), nullptr, 10) : (3ULL << 29);
+	std::vector<std::pair<u32, u32>> todo;	// stack of [qa, qb)
+	{
+		std::vector<std::pair<u32, u32>> chunks;
+		u32 qa = 0;
+		while (qa < nq)
+		{
+			u32 qb = qa + 1;
+			while (qb < nq && hQKmerOff[qb + 1] - hQKmerOff[qa] <= kmerBudget) ++qb;
+			chunks.push_back({qa, qb});
+			qa = qb;
+		}
+		for (size_t i = chunks.size(); i-- > 0;) todo.push_back(chunks[i]);
+	}
+	std::vector<PrimRec> primStore;		// only used when there is more than one chunk
+	std::vector<u64> primOffAll(nq + 1, 0);
+	const bool single = todo.size() == 1;
+	u64 nPrim = 0;
+	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0;
+	bool usedStore = false;
+	while (!todo.empty())
+	{
+		const auto [qa, qb] = todo.back();
+		todo.pop_back();
+		ChunkResult cr;
+		if (!deviceChunk(c, p, forceLocal, hq.data(), hQKmerOff.data(), qa, qb, hitBudget, &cr))
+		{
+			const u32 mid = qa + (qb - qa) / 2;
+			todo.push_back({mid, qb});
+			todo.push_back({qa, mid});
+			continue;
+		}
+		out->seed_hits += cr.nHits; out->dp_groups += cr.dpGroups; out->dp_elements += cr.dpElems;
+		const u64* off = c->hOff.p;
+		for (u32 i = 0; i < qb - qa; ++i) primOffAll[qa + i + 1] = nPrim + off[i + 1];
+		if (!(single && todo.empty() && !usedStore))
+		{
+			usedStore = true;
+			const PrimRec* src = (const PrimRec*)c->hPrim.p;
+			primStore.insert(primStore.end(), src, src + cr.nPrim);
+		}
+		nPrim += cr.nPrim;
+	}
 	HIP_CHECK(hipEventRecord(evB, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	out->dp_groups = 0; out->dp_elements = 0;
-	for (u32 i = 0; i < nq; ++i) { out->dp_groups += hDpG[i]; out->dp_elements += hDpE[i]; }
+	const PrimRec* hPrim = usedStore ? primStore.data() : (const PrimRec*)c->hPrim.p;
+	const u64* hPrimOff = primOffAll.data();
 	const auto tHost1 = std::chrono::steady_clock::now();
 
 	// ---- host shim: floats with the host libm, the gate, prefix rule, window stats ----

@@ -170,6 +170,28 @@ def test_container_mirror_and_divergence_threshold(built, golden_cases):
     assert one.tobytes() == f.tobytes()
 
 
+def test_internal_chunking_is_invisible(built, monkeypatch):
+    """fg_overlaps cuts big batches into chunks bounded by k-mers / seed hits (and halves a
+    chunk whose hits exceed the budget); results must not depend on the cut."""
+    from flye_amd import config, gpu, synth
+    rs = synth.simulate(seed=21, genome_len=60_000, coverage=25, kind="pb_raw").filter_min_len(1000)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    q = np.arange(0, 2 * rs.n, dtype=np.uint32)
+    whole = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+    base = (whole.recs.tobytes(), whole.query_off.tobytes(), whole.stats.tobytes(), whole.seed_hits,
+            whole.dp_groups, whole.dp_elements)
+    for kb, hb in ((200_000, 1 << 40), (1 << 40, 50_000), (90_000, 30_000)):
+        monkeypatch.setenv("FG_KMER_BUDGET", str(kb))
+        monkeypatch.setenv("FG_HIT_BUDGET", str(hb))
+        part = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+        got = (part.recs.tobytes(), part.query_off.tobytes(), part.stats.tobytes(), part.seed_hits,
+               part.dp_groups, part.dp_elements)
+        assert got == base, (kb, hb)
+    monkeypatch.delenv("FG_KMER_BUDGET")
+    monkeypatch.delenv("FG_HIT_BUDGET")
+
+
 def test_edge_cases(built):
     from flye_amd import config, gpu, synth
     cfg = config.preset("raw")
