@@ -181,7 +181,7 @@ struct fg_ctx {
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
 	DevBuf<u32> dCur, dExt;		// (cur, ext) columns of the groups in DP order
 	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
-	DevBuf<char> dSortTasks;
+	DevBuf<char> dSortTasks, dSortBig;
 	DevBuf<int> dEditScratch;
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;

@@ -214,78 +214,92 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 }
 
 // ---- exact std::sort order of every query's hits (fg_wavesort.h) ---------------------
-// Two kernels.  k_sort_top: one wave per query runs the top of the introsort recursion in
-// global memory (L2-resident) until a piece fits SORT_CAP elements and queues it;
-// k_sort_lds: one wave per queued piece finishes it entirely in LDS.
+// The introsort recursion is run level by level over ALL queries of the chunk: every piece
+// larger than SORT_CAP is one task of k_sort_level (one wave = one Hoare partition in global
+// memory, L2-resident), its two halves become tasks of the next level, pieces that fit
+// SORT_CAP elements are queued for k_sort_lds (one wave per piece, entirely in LDS).  A read
+// with 10^5..10^6 hits thus spreads over more waves at every level instead of serialising
+// ~10 levels on one wave.
 #define SORT_CAP 512
 #define SORT_LDS_WAVES 4
 struct SortTask { u64 start; u32 n; u32 depth; };
 
-__global__ void k_sort_top(const u64* __restrict__ hitOff, u64* __restrict__ hitKey, u32* __restrict__ hitVal,
-						   u32 nq, u32* __restrict__ posScratch, u64 nHits, SortTask* __restrict__ tasks,
-						   u32 taskCap, u32* __restrict__ taskCount)
+// block-aggregated append (one atomic per list and block)
+__device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTask* __restrict__ big,
+										   SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
 {
-	__shared__ int stack[WG / 64][3 * 40];
-	__shared__ int small[WG / 64][3 * 8];
-	const int wv = threadIdx.x >> 6;
-	const int lane = threadIdx.x & 63;
-	const u32 q = blockIdx.x * (WG / 64) + wv;
-	if (q >= nq) return;
-	const u64 base = hitOff[q];
-	const u64 n64 = hitOff[q + 1] - base;
-	if (n64 < 2) return;
-	u64* K = hitKey + base;
-	u32* V = hitVal + base;
-	u32* posL = posScratch + base;
-	u32* posR = posScratch + nHits + base;
-	int* stk = stack[wv];
-	int sp = 0;
-	int first = 0, last = (int)n64, depth = 2 * fgsort::floor_log2_((int)n64);
-	while (true)
+	__shared__ u32 wcnt[2][WG / 64];
+	__shared__ u32 base[2];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const bool isBig = valid && t.n > SORT_CAP;
+	const bool isSmall = valid && t.n >= 2 && t.n <= SORT_CAP;
+	const u64 mB = __ballot(isBig), mS = __ballot(isSmall);
+	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mB); wcnt[1][wv] = (u32)__popcll(mS); }
+	__syncthreads();
+	if (threadIdx.x < 2)
 	{
-		bool handled = false;
-		if (last - first <= SORT_CAP)
-		{
-			if (last - first >= 2)
-			{
-				u32 idx = 0;
-				if (lane == 0) idx = atomicAdd(taskCount, 1u);
-				idx = __shfl(idx, 0);
-				if (idx < taskCap)
-				{
-					if (lane == 0) tasks[idx] = SortTask{base + (u64)first, (u32)(last - first), (u32)depth};
-				}
-				else	// queue full: finish the piece here (slow path)
-					wsort::wave_sort<u64, u32>(K, V, last - first, posL, posR, stk + sp, small[wv], first, depth);
-			}
-			handled = true;
-		}
-		else if (depth == 0)
-		{
-			wsort::wave_mem_fence();
-			if (lane == 0) { wsort::PtrAcc<u64> acc{K, V}; fgsort::heap_sort_(acc, first, last); }
-			wsort::wave_mem_fence();
-			handled = true;
-		}
-		if (!handled)
-		{
-			--depth;
-			const int cut = wsort::partition_big<u64, u32>(K, V, first, last, posL + first, posR + first);
-			if (cut - first < last - cut)
-			{
-				stk[sp++] = cut; stk[sp++] = last; stk[sp++] = depth;
-				last = cut;
-			}
-			else
-			{
-				stk[sp++] = first; stk[sp++] = cut; stk[sp++] = depth;
-				first = cut;
-			}
-			continue;
-		}
-		if (sp == 0) break;
-		depth = stk[--sp]; last = stk[--sp]; first = stk[--sp];
+		u32 tot = 0;
+		for (int i = 0; i < WG / 64; ++i) tot += wcnt[threadIdx.x][i];
+		base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], tot) : 0u;
 	}
+	__syncthreads();
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+	u32 oB = base[0], oS = base[1];
+	for (int i = 0; i < wv; ++i) { oB += wcnt[0][i]; oS += wcnt[1][i]; }
+	if (isBig) big[oB + __popcll(mB & below)] = t;
+	if (isSmall)
+	{
+		const u32 slot = oS + __popcll(mS & below);
+		if (slot < smallCap) small[slot] = t;	// counts[1] keeps the true total; see k_sort_overflow
+	}
+	__syncthreads();
+}
+
+__global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __restrict__ big,
+							SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
+{
+	const u32 q = blockIdx.x * WG + threadIdx.x;
+	SortTask t{0, 0, 0};
+	if (q < nq)
+	{
+		const u64 n = hitOff[q + 1] - hitOff[q];
+		t.start = hitOff[q]; t.n = (u32)n; t.depth = n >= 2 ? 2 * fgsort::floor_log2_((int)n) : 0;
+	}
+	sort_route(t, q < nq, big, small, smallCap, counts);
+}
+
+// one wave per task: one partition (or the depth-limit heapsort); children to slots 2i, 2i+1
+__global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, u64* __restrict__ hitKey,
+							 u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
+							 SortTask* __restrict__ children)
+{
+	const int lane = threadIdx.x & 63;
+	const u32 ti = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+	if (ti >= nTasks) return;
+	const SortTask t = tasks[ti];
+	u64* K = hitKey + t.start;
+	u32* V = hitVal + t.start;
+	SortTask c0{0, 0, 0}, c1{0, 0, 0};
+	if (t.depth == 0)
+	{
+		if (lane == 0) { wsort::PtrAcc<u64> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+	}
+	else
+	{
+		const int cut = wsort::partition_big<u64, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
+		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
+	}
+	if (lane == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
+}
+
+__global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildren, SortTask* __restrict__ big,
+							 SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
+{
+	const u32 i = blockIdx.x * WG + threadIdx.x;
+	SortTask t{0, 0, 0};
+	if (i < nChildren) t = children[i];
+	sort_route(t, i < nChildren, big, small, smallCap, counts);
 }
 
 __global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
@@ -403,25 +417,54 @@ T fetchScalar(fg_ctx* c, const T* dptr)
 
 } // namespace
 
+// std::sort order of each segment [segOff[i], segOff[i+1]) of device arrays K, V
+static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* dV, u64 nHits)
+{
+	hipStream_t s = c->stream;
+	// pieces are disjoint; even the median-of-3 killer stays far below one task per 8 hits
+	const u32 smallCap = (u32)std::min<u64>(nHits / 8 + 4ULL * nSeg + 1024, 0x7fffffffULL);
+	const u64 bigCap = nHits / SORT_CAP + nSeg + 16;
+	c->dTmp32.reserve(2 * nHits + 2);
+	c->dSortTasks.reserve((size_t)smallCap * sizeof(SortTask));
+	c->dSortBig.reserve((size_t)(4 * bigCap) * sizeof(SortTask));
+	c->dListCnt.reserve(4);
+	SortTask* smallT = (SortTask*)c->dSortTasks.p;
+	SortTask* bigA = (SortTask*)c->dSortBig.p;
+	SortTask* bigB = bigA + bigCap;
+	SortTask* kids = bigB + bigCap;	// 2 * bigCap
+	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
+	{ ScopedK t(c->timer, "k_sort_level");
+	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, bigA, smallT, smallCap, c->dListCnt.p); }
+	u32 nBig = fetchScalar(c, c->dListCnt.p);
+	while (nBig)
+	{
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
+		ScopedK t(c->timer, "k_sort_level");
+		hipLaunchKernelGGL(k_sort_level, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids);
+		hipLaunchKernelGGL(k_sort_route, (2 * nBig + WG - 1) / WG, WG, 0, s, kids, 2 * nBig, bigB, smallT, smallCap, c->dListCnt.p);
+		nBig = fetchScalar(c, c->dListCnt.p);
+		std::swap(bigA, bigB);
+	}
+	const u32 nTasks = fetchScalar(c, c->dListCnt.p + 1);
+	if (nTasks > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
+	if (nTasks)
+	{
+		ScopedK t(c->timer, "k_sort_lds");
+		hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+						   smallT, c->dListCnt.p + 1, smallCap, dK, dV);
+	}
+}
+
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg)
 {
 	hipStream_t s = c->stream;
 	const u64 n = segOff[nSeg];
-	DevBuf<u64> dK, dOff; DevBuf<u32> dV, dPos, dCnt; DevBuf<SortTask> dTasks;
-	// a deliberately small queue so that the "queue full" path is exercised too
-	const u32 taskCap = (u32)(n / 64 + nSeg / 2 + 16);
-	dK.alloc(n + 1); dV.alloc(n + 1); dOff.alloc(nSeg + 1); dPos.alloc(2 * n + 2); dCnt.alloc(1); dTasks.alloc(taskCap);
+	DevBuf<u64> dK, dOff; DevBuf<u32> dV;
+	dK.alloc(n + 1); dV.alloc(n + 1); dOff.alloc(nSeg + 1);
 	HIP_CHECK(hipMemcpyAsync(dK.p, keys, n * 8, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dV.p, vals, n * 4, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dOff.p, segOff, (nSeg + 1) * 8ULL, hipMemcpyHostToDevice, s));
-	HIP_CHECK(hipMemsetAsync(dCnt.p, 0, 4, s));
-	if (nSeg)
-	{
-		hipLaunchKernelGGL(k_sort_top, (nSeg + WG / 64 - 1) / (WG / 64), WG, 0, s, dOff.p, dK.p, dV.p, nSeg, dPos.p, n,
-						   dTasks.p, taskCap, dCnt.p);
-		hipLaunchKernelGGL(k_sort_lds, (taskCap + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-						   dTasks.p, dCnt.p, taskCap, dK.p, dV.p);
-	}
+	if (nSeg) sortSegments(c, dOff.p, nSeg, dK.p, dV.p, n);
 	HIP_CHECK(hipMemcpyAsync(keys, dK.p, n * 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(vals, dV.p, n * 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -465,24 +508,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	{ ScopedK t(c->timer, "k_fill");
 	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
 						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
-	{
-		const u64 cap64 = nHits / 8 + 4ULL * nq + 1024;
-		const u32 taskCap = (u32)std::min<u64>(cap64, 0x7fffffffULL);
-		c->dTmp32.reserve(2 * nHits + 2);
-		c->dSortTasks.reserve((size_t)taskCap * sizeof(SortTask));
-		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
-		{ ScopedK t(c->timer, "k_sort_top");
-		  hipLaunchKernelGGL(k_sort_top, (nq + WG / 64 - 1) / (WG / 64), WG, 0, s, c->dHitOff.p, c->dHitKey.p,
-							 c->dHitVal.p, nq, c->dTmp32.p, nHits, (SortTask*)c->dSortTasks.p, taskCap, c->dListCnt.p); }
-		u32 nTasks = fetchScalar(c, c->dListCnt.p);
-		nTasks = std::min(nTasks, taskCap);
-		if (nTasks)
-		{
-			ScopedK t(c->timer, "k_sort_lds");
-			hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-							   (const SortTask*)c->dSortTasks.p, c->dListCnt.p, taskCap, c->dHitKey.p, c->dHitVal.p);
-		}
-	}
+	sortSegments(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits);
 	{ ScopedK t(c->timer, "k_group_count");
 	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");
