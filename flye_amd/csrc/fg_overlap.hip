@@ -271,7 +271,7 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 // one wave per task: one partition (or the depth-limit heapsort); children to slots 2i, 2i+1
 __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, u64* __restrict__ hitKey,
 							 u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
-							 SortTask* __restrict__ children)
+							 SortTask* __restrict__ children, u32 streamMax)
 {
 	const int lane = threadIdx.x & 63;
 	const u32 ti = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
@@ -286,7 +286,11 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, u64
 	}
 	else
 	{
-		const int cut = wsort::partition_big<u64, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+		// many medium pieces in flight: the streamed form moves fewer bytes; few huge pieces:
+		// the closed form has no serial chain
+		const int cut = t.n <= streamMax
+			? wsort::partition_stream<u64>(K, V, 0, (int)t.n)
+			: wsort::partition_big<u64, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
 		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
 		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
 	}
@@ -432,6 +436,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* 
 	SortTask* bigA = (SortTask*)c->dSortBig.p;
 	SortTask* bigB = bigA + bigCap;
 	SortTask* kids = bigB + bigCap;	// 2 * bigCap
+	const u32 streamMax = getenv("FG_SORT_STREAM_MAX") ? (u32)atoi(getenv("FG_SORT_STREAM_MAX")) : 32768u;
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
 	{ ScopedK t(c->timer, "k_sort_level");
 	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, bigA, smallT, smallCap, c->dListCnt.p); }
@@ -440,7 +445,8 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* 
 	{
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
 		ScopedK t(c->timer, "k_sort_level");
-		hipLaunchKernelGGL(k_sort_level, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids);
+		hipLaunchKernelGGL(k_sort_level, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids,
+						   streamMax);
 		hipLaunchKernelGGL(k_sort_route, (2 * nBig + WG - 1) / WG, WG, 0, s, kids, 2 * nBig, bigB, smallT, smallCap, c->dListCnt.p);
 		nBig = fetchScalar(c, c->dListCnt.p);
 		std::swap(bigA, bigB);
