@@ -373,8 +373,11 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
 	}
 
-	if (lane != 0 || (P.ablate & 8)) return;
-	// backtracking with consumption, overlapTest, primary selection: one lane
+	if (P.ablate & 8) return;
+	// backtracking with consumption, overlapTest, primary selection.  Consumption only ever
+	// turns back[] entries into -1, so a start whose entry already is -1 can be skipped for good:
+	// the wave screens 64 order entries at once and lane 0 walks only the survivors (re-checking
+	// each, since a chain walked in between may have consumed it).
 	const u32 qrec = query[q];
 	const u32 curId = P.firstId + qrec;
 	const u32 extId = (u32)(hitKey[g0] >> 32);
@@ -383,27 +386,42 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	int4* cd = cand + g0;
 	i32 ncand = 0;
 	int4 best = make_int4(0, 0, 0, 0);
-	for (i32 oi = 0; oi < n; ++oi)
+	wsort::wave_mem_fence();
+	for (i32 oi0 = 0; oi0 < n; oi0 += 64)
 	{
-		const i32 start = (i32)oval[oi];
-		if (back[start] == -1) continue;
-		i32 firstM = 0, chainLength = 0, pos = start;
-		while (pos != -1)
+		const bool in = oi0 + lane < n;
+		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
+		const i32 bk = in ? back[st] : -1;
+		u64 m = __ballot(bk != -1);
+		while (m)
 		{
-			firstM = pos;
-			++chainLength;
-			const i32 np = back[pos];
-			back[pos] = -1;
-			pos = np;
+			const int l = __ffsll((long long)m) - 1;
+			m &= m - 1;
+			const i32 start = __builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(l));
+			if (lane == 0 && back[start] != -1)
+			{
+				i32 firstM = 0, chainLength = 0, pos = start;
+				while (pos != -1)
+				{
+					firstM = pos;
+					++chainLength;
+					const i32 np = back[pos];
+					back[pos] = -1;
+					pos = np;
+				}
+				const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
+				const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
+				if (overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee))
+				{
+					const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
+					cd[ncand] = c4;
+					if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
+					++ncand;
+				}
+			}
 		}
-		const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
-		const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
-		if (!overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee)) continue;
-		const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
-		cd[ncand] = c4;
-		if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
-		++ncand;
 	}
+	if (lane != 0) return;
 	if (ncand == 0) return;
 	if (ncand > 16)
 	{

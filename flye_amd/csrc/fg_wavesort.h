@@ -164,22 +164,26 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	int pos = lane;
 	if (!(g_ablate & 32))
 	{
-		KT rk = key; int rid = lane;
+		// Each pair of lanes at distance <= 15 is compared once: a copy of every element
+		// travels 15 lanes in one direction; the lane it visits and the visitor both book the
+		// outcome (the visitor in `acc`), and `acc` is brought home by one bpermute.  The
+		// visitor's lane id travels along, so nothing depends on the rotation direction.
+		KT vk = key; int vid = lane; int acc = 0;
 		for (int d = 0; d < 15; ++d)
 		{
-			rk = rot_key<0x13C>(rk); rid = __builtin_amdgcn_update_dpp(0, rid, 0x13C, 0xf, 0xf, false);
-			const int dist = rid - lane;
-			if (rid < n && dist >= -15 && dist < 0) pos -= (rk > key);
-			if (rid < n && dist > 0 && dist <= 15) pos += (rk < key);
+			vk = rot_key<0x13C>(vk);
+			vid = __builtin_amdgcn_update_dpp(0, vid, 0x13C, 0xf, 0xf, false);
+			acc = __builtin_amdgcn_update_dpp(0, acc, 0x13C, 0xf, 0xf, false);
+			const int dist = vid - lane;
+			const bool ok = vid < n && lane < n && dist >= -15 && dist <= 15;
+			const bool fromBelow = dist < 0;
+			// from below: a greater visitor must end up above me; from above: a smaller one below me
+			const int c = (ok && (fromBelow ? (vk > key) : (vk < key))) ? 1 : 0;
+			pos += fromBelow ? -c : c;
+			acc += fromBelow ? c : -c;
 		}
-		rk = key; rid = lane;
-		for (int d = 0; d < 15; ++d)
-		{
-			rk = rot_key<0x134>(rk); rid = __builtin_amdgcn_update_dpp(0, rid, 0x134, 0xf, 0xf, false);
-			const int dist = rid - lane;
-			if (rid < n && dist >= -15 && dist < 0) pos -= (rk > key);
-			if (rid < n && dist > 0 && dist <= 15) pos += (rk < key);
-		}
+		const int delta = __builtin_amdgcn_readfirstlane((lane - vid) & 63);
+		pos += __shfl(acc, (lane + delta) & 63);
 	}
 	wave_mem_fence();
 	if (lane < n) { K[first + pos] = key; V[first + pos] = val; }
