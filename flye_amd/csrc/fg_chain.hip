@@ -108,14 +108,17 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 	append3(n >= minSize && n > 0, false, false, (u32)g, list, list, list, counts);
 }
 
-#define FIN_CAP 256
-// groups that passed the prefilter, all of them (DP) and by size (finish)
-__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listDp,
-						  u32* __restrict__ listSmall, u32* __restrict__ listBig, u32* __restrict__ counts)
+#define FIN_CAP_S 256		// <= : LDS, 4 groups per block; larger groups run on global scratch.
+// (Measured: staging 257..1024-hit groups in LDS at 2 waves per block, or > 2048-hit groups at
+// one wave per block, is slower than global scratch -- the occupancy lost costs more than the
+// latency saved.)
+// groups that passed the prefilter, by size class
+__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listSmall,
+						  u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
 {
 	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
 	const u32 n = g < nGroups ? dpSize[g] : 0u;
-	append3(n > 0, n > 0 && n <= FIN_CAP, n > FIN_CAP, (u32)g, listDp, listSmall, listBig, counts);
+	append3(n > 0 && n <= FIN_CAP_S, n > FIN_CAP_S, false, (u32)g, listSmall, listMid, listBig, counts);
 }
 
 // ---- prep --------------------------------------------------------------------------------
@@ -322,8 +325,8 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 }
 
 // ---- finish ------------------------------------------------------------------------------
-#define FIN_WAVES 4
-template <bool USE_LDS>
+// CAP = 0: everything in global scratch; otherwise the group (<= CAP hits) is staged in LDS
+template <int CAP, int FIN_WAVES>
 __global__ void __launch_bounds__(FIN_WAVES * 64)
 k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
@@ -333,12 +336,9 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 			   const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
 			   PrimRec* __restrict__ prim, u32* __restrict__ primFlag)
 {
-	__shared__ i32 sScore[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
-	__shared__ i32 sBack[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
-	__shared__ u32 sOKey[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
-	__shared__ u32 sOVal[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
-	__shared__ unsigned short sPL[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
-	__shared__ unsigned short sPR[USE_LDS ? FIN_WAVES : 1][USE_LDS ? FIN_CAP : 1];
+	constexpr bool USE_LDS = CAP > 0;
+	// dynamic LDS: per wave CAP * 20 bytes (score, back, order key, order value, 2 x u16 scratch)
+	extern __shared__ __attribute__((aligned(16))) char finLds[];
 	__shared__ int stack[FIN_WAVES][3 * 40];
 	__shared__ int small[FIN_WAVES][3 * 8];
 	const int wv = threadIdx.x >> 6;
@@ -356,7 +356,8 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	i32 *score, *back; u32 *okey, *oval;
 	if (USE_LDS)
 	{
-		score = sScore[wv]; back = sBack[wv]; okey = sOKey[wv]; oval = sOVal[wv];
+		char* base = finLds + (size_t)wv * CAP * 20;
+		score = (i32*)base; back = score + CAP; okey = (u32*)(back + CAP); oval = okey + CAP;
 		for (i32 i = lane; i < n; i += 64) { score[i] = gScore[g0 + i]; back[i] = gBack[g0 + i]; }
 		wsort::wave_mem_fence();
 	}
@@ -369,7 +370,11 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	wsort::wave_mem_fence();
 	if (!(P.ablate & 2))
 	{
-		if (USE_LDS) wsort::wave_sort<u32, unsigned short>(okey, oval, n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		if (USE_LDS)
+		{
+			unsigned short* pl = (unsigned short*)(oval + CAP);
+			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + CAP, stack[wv], small[wv]);
+		}
 		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
 	}
 
@@ -497,31 +502,32 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 						 c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_dp_list");
-	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListDp.p, c->dListSmall.p,
+	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListSmall.p, c->dListDp.p,
 						 c->dListBig.p, c->dListCnt.p); }
 	u32 hc[3];
 	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	const u32 nDp = hc[0], nSmall = hc[1], nBig = hc[2];
-	if (!nDp) return;
-	{ ScopedK t(c->timer, "k_chain_dp");
-	  hipLaunchKernelGGL(k_chain_dp, (nDp + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, c->dListDp.p, nDp, nGroups, nHits, c->dGroupStart.p,
-						 c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p,
-						 c->dBack.p); }
-	if (nSmall)
+	const u32* lists[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};	// small, mid, big
 	{
-		ScopedK t(c->timer, "k_chain_finish<lds>");
-		hipLaunchKernelGGL(k_chain_finish<true>, (nSmall + FIN_WAVES - 1) / FIN_WAVES, FIN_WAVES * 64, 0, s, cp,
-						   c->dListSmall.p, nSmall, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p,
-						   c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p,
-						   c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p);
+		ScopedK t(c->timer, "k_chain_dp");
+		for (int cls = 1; cls >= 0; --cls)	// the bigger groups first: they set the tail
+			if (hc[cls])
+				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
+								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p,
+								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
 	}
-	if (nBig)
+#define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
+		c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, \
+		prim, c->dPrimFlag.p
+	if (hc[1])
 	{
 		ScopedK t(c->timer, "k_chain_finish<global>");
-		hipLaunchKernelGGL(k_chain_finish<false>, (nBig + FIN_WAVES - 1) / FIN_WAVES, FIN_WAVES * 64, 0, s, cp,
-						   c->dListBig.p, nBig, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p,
-						   c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p,
-						   c->dFiltOff.p, c->dFiltPos.p, prim, c->dPrimFlag.p);
+		hipLaunchKernelGGL((k_chain_finish<0, 4>), (hc[1] + 3) / 4, 256, 0, s, FIN_ARGS(1));
 	}
+	if (hc[0])
+	{
+		ScopedK t(c->timer, "k_chain_finish<lds256>");
+		hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, 4>), (hc[0] + 3) / 4, 256, FIN_CAP_S * 20 * 4, s, FIN_ARGS(0));
+	}
+#undef FIN_ARGS
 }
