@@ -172,6 +172,7 @@ struct fg_ctx {
 	DevBuf<i32> dFiltPos;
 	DevBuf<u64> dHitKey;		// extId<<32 | curPos
 	DevBuf<u32> dHitVal;		// extPos
+	DevBuf<u32> dHitKey32;		// record << curBits | curPos, when that fits 32 bits (sort only)
 	DevBuf<i32> dScore, dBack, dOrder;
 	DevBuf<int4> dCand;
 	DevBuf<u64> dGroupStart;	// group boundaries (indices into hits)

@@ -146,11 +146,15 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 // Per 256 query positions: owners publish (output start, list offset, count, flags) in
 // LDS, then the block walks the OUTPUT slots -- thread o finds its owner by bisection of the
 // starts -- so the 12-byte hit records leave as coalesced stores.
+// KT = u64: key = extId << 32 | curPos.  KT = u32 (when record index and position fit 32 bits
+// together): key = record << curBits | curPos -- same order, a third less sort traffic;
+// k_expand_keys restores the 64-bit form after the sort.
+template <class KT>
 __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len,
-					   const u64* __restrict__ qKmerOff, int k, u32 firstId,
+					   const u64* __restrict__ qKmerOff, int k, u32 firstId, int curBits,
 					   const u64* __restrict__ probe, const u64* __restrict__ entries,
 					   const u64* __restrict__ hitOff, const u64* __restrict__ filtOff,
-					   u64* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ filtPos)
+					   KT* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ filtPos)
 {
 	__shared__ u32 sh[WG / 64 + 1];
 	__shared__ u32 sStart[WG + 1];
@@ -204,7 +208,8 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 			u32 srec = (u32)(e >> 32);
 			i32 spos = (i32)(u32)e;
 			if (so & FLAG_FLIP) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
-			hitKey[hbase + o] = ((u64)(firstId + srec) << 32) | (u32)(p0 + (i32)t);
+			if (sizeof(KT) == 8) hitKey[hbase + o] = (KT)(((u64)(firstId + srec) << 32) | (u32)(p0 + (i32)t));
+			else hitKey[hbase + o] = (KT)((srec << curBits) | (u32)(p0 + (i32)t));
 			hitVal[hbase + o] = (u32)spos;
 		}
 		__syncthreads();
@@ -269,7 +274,8 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 }
 
 // one wave per task: one partition (or the depth-limit heapsort); children to slots 2i, 2i+1
-__global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, u64* __restrict__ hitKey,
+template <class KT>
+__global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hitKey,
 							 u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
 							 SortTask* __restrict__ children, u32 streamMax)
 {
@@ -277,20 +283,20 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, u64
 	const u32 ti = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
 	if (ti >= nTasks) return;
 	const SortTask t = tasks[ti];
-	u64* K = hitKey + t.start;
+	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	SortTask c0{0, 0, 0}, c1{0, 0, 0};
 	if (t.depth == 0)
 	{
-		if (lane == 0) { wsort::PtrAcc<u64> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		if (lane == 0) { wsort::PtrAcc<KT> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
 	}
 	else
 	{
 		// many medium pieces in flight: the streamed form moves fewer bytes; few huge pieces:
 		// the closed form has no serial chain
 		const int cut = t.n <= streamMax
-			? wsort::partition_stream<u64>(K, V, 0, (int)t.n)
-			: wsort::partition_big<u64, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+			? wsort::partition_stream<KT>(K, V, 0, (int)t.n)
+			: wsort::partition_big<KT, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
 		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
 		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
 	}
@@ -306,11 +312,12 @@ __global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildre
 	sort_route(t, i < nChildren, big, small, smallCap, counts);
 }
 
+template <class KT>
 __global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
 k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount, u32 taskCap,
-		   u64* __restrict__ hitKey, u32* __restrict__ hitVal)
+		   KT* __restrict__ hitKey, u32* __restrict__ hitVal)
 {
-	__shared__ u64 sK[SORT_LDS_WAVES][SORT_CAP];
+	__shared__ KT sK[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ u32 sV[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ unsigned short sPL[SORT_LDS_WAVES][SORT_CAP], sPR[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ int stack[SORT_LDS_WAVES][3 * 40];
@@ -322,13 +329,22 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	const u32 ti = blockIdx.x * SORT_LDS_WAVES + wv;
 	if (ti >= nTasks) return;
 	const SortTask t = tasks[ti];
-	u64* K = hitKey + t.start;
+	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	const int n = (int)t.n;
 	for (int i = lane; i < n; i += 64) { sK[wv][i] = K[i]; sV[wv][i] = V[i]; }
 	wsort::wave_mem_fence();
-	wsort::wave_sort<u64, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+	wsort::wave_sort<KT, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
 	for (int i = lane; i < n; i += 64) { K[i] = sK[wv][i]; V[i] = sV[wv][i]; }
+}
+
+// 32-bit sort keys back to extId << 32 | curPos
+__global__ void k_expand_keys(const u32* __restrict__ k32, u64 n, int curBits, u32 firstId, u64* __restrict__ k64)
+{
+	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	const u32 v = k32[i];
+	k64[i] = ((u64)(firstId + (v >> curBits)) << 32) | (v & ((1u << curBits) - 1u));
 }
 
 // ---- target groups ---------------------------------------------------------------------
@@ -422,7 +438,8 @@ T fetchScalar(fg_ctx* c, const T* dptr)
 } // namespace
 
 // std::sort order of each segment [segOff[i], segOff[i+1]) of device arrays K, V
-static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* dV, u64 nHits)
+template <class KT>
+static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* dV, u64 nHits)
 {
 	hipStream_t s = c->stream;
 	// pieces are disjoint; even the median-of-3 killer stays far below one task per 8 hits
@@ -445,7 +462,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* 
 	{
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
 		ScopedK t(c->timer, "k_sort_level");
-		hipLaunchKernelGGL(k_sort_level, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids,
+		hipLaunchKernelGGL(k_sort_level<KT>, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids,
 						   streamMax);
 		hipLaunchKernelGGL(k_sort_route, (2 * nBig + WG - 1) / WG, WG, 0, s, kids, 2 * nBig, bigB, smallT, smallCap, c->dListCnt.p);
 		nBig = fetchScalar(c, c->dListCnt.p);
@@ -456,7 +473,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, u64* dK, u32* 
 	if (nTasks)
 	{
 		ScopedK t(c->timer, "k_sort_lds");
-		hipLaunchKernelGGL(k_sort_lds, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+		hipLaunchKernelGGL(k_sort_lds<KT>, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
 						   smallT, c->dListCnt.p + 1, smallCap, dK, dV);
 	}
 }
@@ -470,7 +487,7 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 	HIP_CHECK(hipMemcpyAsync(dK.p, keys, n * 8, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dV.p, vals, n * 4, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(dOff.p, segOff, (nSeg + 1) * 8ULL, hipMemcpyHostToDevice, s));
-	if (nSeg) sortSegments(c, dOff.p, nSeg, dK.p, dV.p, n);
+	if (nSeg) sortSegments<u64>(c, dOff.p, nSeg, dK.p, dV.p, n);
 	HIP_CHECK(hipMemcpyAsync(keys, dK.p, n * 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(vals, dV.p, n * 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
@@ -511,10 +528,32 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	if (nHits > hitBudget && nq > 1) return false;
 	res->nHits = nHits;
 	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
-	{ ScopedK t(c->timer, "k_fill");
-	  hipLaunchKernelGGL(k_fill, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, c->dProbe.p,
-						 c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
-	sortSegments(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits);
+	// 32-bit sort keys when (record index, query position) fit together
+	int curBits = 1, recBits = 1;
+	while ((1LL << curBits) < (long long)c->maxLen) ++curBits;
+	while ((1ULL << recBits) < 2ULL * c->nReads) ++recBits;
+	const bool key32 = curBits + recBits <= 32 && !getenv("FG_FORCE_KEY64");
+	if (key32)
+	{
+		c->dHitKey32.reserve(nHits + 1);
+		{ ScopedK t(c->timer, "k_fill");
+		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, curBits,
+							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
+		sortSegments<u32>(c, c->dHitOff.p, nq, c->dHitKey32.p, c->dHitVal.p, nHits);
+		if (nHits)
+		{
+			ScopedK t(c->timer, "k_expand_keys");
+			hipLaunchKernelGGL(k_expand_keys, (unsigned)((nHits + WG - 1) / WG), WG, 0, s, c->dHitKey32.p, nHits, curBits,
+							   c->firstId, c->dHitKey.p);
+		}
+	}
+	else
+	{
+		{ ScopedK t(c->timer, "k_fill");
+		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, 0,
+							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
+		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits);
+	}
 	{ ScopedK t(c->timer, "k_group_count");
 	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");

@@ -190,6 +190,11 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
         assert got == base, (kb, hb)
     monkeypatch.delenv("FG_KMER_BUDGET")
     monkeypatch.delenv("FG_HIT_BUDGET")
+    # 64-bit sort keys (used when record index + position do not fit 32 bits) give the same result
+    monkeypatch.setenv("FG_FORCE_KEY64", "1")
+    k64 = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+    assert (k64.recs.tobytes(), k64.query_off.tobytes(), k64.stats.tobytes()) == base[:3]
+    monkeypatch.delenv("FG_FORCE_KEY64")
 
 
 def test_edge_cases(built):
