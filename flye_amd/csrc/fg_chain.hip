@@ -228,6 +228,7 @@ __device__ __forceinline__ i32 wave_incl_max(i32 v)
 // registers, the results leave the same way; only look-backs deeper than 64 (about 1.6 %
 // of the elements on PacBio-raw data) read memory.
 #define DP_WAVES 4
+#define DP_RING 256
 __global__ void __launch_bounds__(DP_WAVES * 64)
 k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
@@ -252,7 +253,13 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	const int k = P.k;
 	const i32 maxJump = P.maxJump;
 
-	// tile = 64 consecutive elements, one per lane; results of the tile; next tile prefetched
+	// tile = 64 consecutive elements, one per lane; results of the tile; next tile prefetched.
+	// Completed tiles are also kept in a per-wave LDS ring (the last DP_RING elements) so that
+	// look-backs deeper than the register window rarely touch global memory.
+	__shared__ i32 ring[DP_WAVES][3][DP_RING];
+	i32* ringC = ring[threadIdx.x >> 6][0];
+	i32* ringE = ring[threadIdx.x >> 6][1];
+	i32* ringS = ring[threadIdx.x >> 6][2];
 	i32 tc = lane < n ? (i32)cur[lane] : 0, te = lane < n ? (i32)ext[lane] : 0;
 	i32 ntc = 64 + lane < n ? (i32)cur[64 + lane] : 0, nte = 64 + lane < n ? (i32)ext[64 + lane] : 0;
 	i32 rs = 0, rb = -1;	// element 0: score 0, no predecessor
@@ -263,6 +270,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 		{
 			const i32 tb = i - 64;
 			score[tb + lane] = rs; back[tb + lane] = rb;
+			ringC[(tb + lane) & (DP_RING - 1)] = tc; ringE[(tb + lane) & (DP_RING - 1)] = te; ringS[(tb + lane) & (DP_RING - 1)] = rs;
 			tc = ntc; te = nte;
 			ntc = i + 64 + lane < n ? (i32)cur[i + 64 + lane] : 0;
 			nte = i + 64 + lane < n ? (i32)ext[i + 64 + lane] : 0;
@@ -278,17 +286,25 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 			i32 cp = wc, ep = we, sj = ws;
 			if (jb != i - 1)
 			{
-				// deeper than the register window: rare; the scores were stored by this wave
-				__builtin_amdgcn_s_waitcnt(0);
+				// deeper than the register window: current tile from registers, the previous
+				// DP_RING elements from LDS, anything older from memory (stored by this wave)
+				const i32 tileBase = i & ~63;
+				const i32 inC = __shfl(tc, j & 63), inE = __shfl(te, j & 63), inS = __shfl(rs, j & 63);
 				cp = 0; ep = 0; sj = 0;
 				if (valid)
 				{
-					cp = (i32)cur[j]; ep = (i32)ext[j];
-					sj = (j >= (i & ~63)) ? 0 : __hip_atomic_load(&score[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (j >= tileBase) { cp = inC; ep = inE; sj = inS; }
+					else if (j >= tileBase - DP_RING)
+					{
+						cp = ringC[j & (DP_RING - 1)]; ep = ringE[j & (DP_RING - 1)]; sj = ringS[j & (DP_RING - 1)];
+					}
+					else
+					{
+						__builtin_amdgcn_s_waitcnt(0);
+						cp = (i32)cur[j]; ep = (i32)ext[j];
+						sj = __hip_atomic_load(&score[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
 				}
-				// elements of the current tile are still in registers (rs), not in memory
-				const i32 inTile = __shfl(rs, j & 63);
-				if (valid && j >= (i & ~63)) sj = inTile;
 			}
 			// straight-line (no exec-mask branches): unsigned range tests, selects
 			const i32 dc = cn - cp, de = en - ep;
