@@ -524,13 +524,15 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
 	const u32* lists[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};	// small, mid, big
+	for (int cls = 1; cls >= 0; --cls)	// the bigger groups first: they set the tail
 	{
-		ScopedK t(c->timer, "k_chain_dp");
-		for (int cls = 1; cls >= 0; --cls)	// the bigger groups first: they set the tail
 			if (hc[cls])
+			{
+				ScopedK t(c->timer, "k_chain_dp");
 				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
 								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p,
 								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
+			}
 	}
 #define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
 		c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, \

@@ -30,8 +30,9 @@ def dmel_ont30(seed=3, scale=1.0):
 
 def hifi30(seed=5, genome_len=4_640_000):
     """HiFi-parameter workload (asm_hifi.cfg) on an E. coli sized genome."""
+    scale = genome_len / 4_640_000
     rs = synth.simulate(seed=seed, genome_len=genome_len, coverage=30, kind="hifi03",
-                        n_repeat_families=8, repeat_len=(1300, 5000), repeat_copies=(5, 9),
-                        n_homopolymers=400, n_tandems=300)
+                        n_repeat_families=max(1, int(round(8 * scale))), repeat_len=(1300, 5000),
+                        repeat_copies=(5, 9), n_homopolymers=int(400 * scale), n_tandems=int(300 * scale))
     min_ovlp = config.min_overlap_from_reads(rs.length, "hifi")
     return rs.filter_min_len(min_ovlp), min_ovlp, "hifi"
