@@ -104,6 +104,7 @@ int fg_set_reads(fg_ctx* c, uint32_t n, const uint64_t* words, const uint64_t* w
 		HIP_CHECK(hipSetDevice(c->device));
 		if ((u64)first_seq_id + 2ULL * n > 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "sequence ids overflow uint32"};
 		c->indexBuilt = false;
+		c->hasQ = false; c->nQReads = 0; c->hQLen.clear();
 		c->nReads = n;
 		c->firstId = first_seq_id;
 		c->totalWords = n ? word_off[n] : 0;
@@ -134,6 +135,40 @@ int fg_set_reads(fg_ctx* c, uint32_t n, const uint64_t* words, const uint64_t* w
 			HIP_CHECK(hipMemcpyAsync(c->dLen.p, len, n * 4ULL, hipMemcpyHostToDevice, s));
 		}
 		HIP_CHECK(hipMemcpyAsync(c->dKmerOff.p, c->hKmerOff.data(), (n + 1) * 8ULL, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	});
+}
+
+int fg_set_queries(fg_ctx* c, uint32_t n, const uint64_t* words, const uint64_t* word_off,
+				   const int32_t* len, uint32_t first_seq_id)
+{
+	if (!c || (n && (!words || !word_off || !len))) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		c->hasQ = n > 0;
+		c->nQReads = n; c->qFirstId = first_seq_id; c->qMaxLen = 0;
+		c->hQLen.clear();
+		if (!n) { c->dQWords.release(); c->dQWordOff.release(); c->dQLen.release(); return; }
+		if ((u64)first_seq_id + 2ULL * n > 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "sequence ids overflow uint32"};
+		// the reference hands out ids from one process-wide counter: the two containers never share ids
+		const u64 a0 = c->firstId, a1 = (u64)c->firstId + 2ULL * c->nReads, b0 = first_seq_id, b1 = (u64)first_seq_id + 2ULL * n;
+		if (a0 < b1 && b0 < a1) throw FgError{FG_ERR_ARG, "query ids overlap the ids of the indexed container"};
+		c->hQLen.assign(len, len + n);
+		for (u32 i = 0; i < n; ++i)
+		{
+			if (len[i] < 0) throw FgError{FG_ERR_ARG, "negative read length"};
+			if ((u64)(len[i] + 31) / 32 > word_off[i + 1] - word_off[i])
+				throw FgError{FG_ERR_ARG, "word_off does not cover query " + std::to_string(i)};
+			c->qMaxLen = std::max(c->qMaxLen, len[i]);
+		}
+		const u64 nw = word_off[n];
+		c->dQWords.alloc(nw + 2); c->dQWordOff.alloc(n + 1); c->dQLen.alloc(n);
+		hipStream_t s = c->stream;
+		HIP_CHECK(hipMemsetAsync(c->dQWords.p + nw, 0, 16, s));
+		HIP_CHECK(hipMemcpyAsync(c->dQWords.p, words, nw * 8, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(c->dQWordOff.p, word_off, (n + 1) * 8ULL, hipMemcpyHostToDevice, s));
+		HIP_CHECK(hipMemcpyAsync(c->dQLen.p, len, n * 4ULL, hipMemcpyHostToDevice, s));
 		HIP_CHECK(hipStreamSynchronize(s));
 	});
 }
@@ -199,10 +234,14 @@ int fg_overlaps(fg_ctx* c, const struct fg_detector_params* p, const uint32_t* q
 	if (!c || !p || !out || (n_queries && !query_ids)) return FG_ERR_ARG;
 	memset(out, 0, sizeof(*out));
 	if (!c->indexBuilt) return FG_ERR_STATE;
-	if (p->keep_alignment || p->partition_bad_mappings || !p->only_max_ext) return FG_ERR_UNSUPPORTED;
+	if (p->keep_alignment || p->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
 	if (p->max_jump <= 0 || p->min_overlap <= 0 || max_overlaps < 0) return FG_ERR_ARG;
-	for (u32 i = 0; i < n_queries; ++i)
-		if (query_ids[i] < c->firstId || query_ids[i] - c->firstId >= 2 * c->nReads) return FG_ERR_ARG;
+	{
+		const u32 base = c->hasQ ? c->qFirstId : c->firstId;
+		const u32 cnt = c->hasQ ? c->nQReads : c->nReads;
+		for (u32 i = 0; i < n_queries; ++i)
+			if (query_ids[i] < base || query_ids[i] - base >= 2 * cnt) return FG_ERR_ARG;
+	}
 	const int rc = guarded(c, [&]()
 	{
 		HIP_CHECK(hipSetDevice(c->device));

@@ -24,7 +24,9 @@ struct ChainParams {
 	int k, maxJump, minOverlap, maxOverhang;
 	int checkOverhang, forceLocal;
 	float minUnique;	// minKmerSruvivalRate * _minOverlap as a float (overlap.cpp:110, :235)
-	u32 firstId;
+	u32 firstId;		// FastaRecord id of the first indexed record
+	u32 qFirstId;		// ... of the first query record (= firstId unless a query container is set)
+	int onlyMaxExt;
 	int ablate;			// timing experiments only (FG_ABLATE env; results become wrong)
 };
 
@@ -93,14 +95,14 @@ __device__ __forceinline__ void append3(bool a, bool b, bool c, u32 g, u32* list
 
 // groups that can still have >= minUnique distinct query positions (unique <= size)
 __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
-							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primFlag,
+							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primCount,
 							 u32* __restrict__ dpSize)
 {
 	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
 	u64 n = 0;
 	if (g < nGroups)
 	{
-		primFlag[g] = 0;
+		primCount[g] = 0;
 		dpSize[g] = 0;
 		const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
 		n = gend - groupStart[g];
@@ -127,7 +129,7 @@ __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __re
 __global__ void __launch_bounds__(PREP_WAVES * 64)
 k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-			 const u32* __restrict__ query, const i32* __restrict__ len,
+			 const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
 			 const u64* __restrict__ hitKey, const u32* __restrict__ hitVal,
 			 u32* __restrict__ gCur, u32* __restrict__ gExt, u32* __restrict__ gAux /* 4 u32 per hit */,
 			 u32* __restrict__ dpSize)
@@ -168,7 +170,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	if ((float)uniq < P.minUnique) return;
 	const u32 qrec = query[groupQuery[g]];
 	const u32 extRec = (u32)(K[0] >> 32) - P.firstId;
-	const i32 curLen = len[qrec >> 1];
+	const i32 curLen = qLen[qrec >> 1];
 	const i32 extLen = len[extRec >> 1];
 	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
 	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
@@ -232,7 +234,8 @@ __device__ __forceinline__ i32 wave_incl_max(i32 v)
 __global__ void __launch_bounds__(DP_WAVES * 64)
 k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-		   const u32* __restrict__ query, const i32* __restrict__ len, const u64* __restrict__ hitKey,
+		   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
+		   const u64* __restrict__ hitKey,
 		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
 		   i32* __restrict__ gScore, i32* __restrict__ gBack)
 {
@@ -245,7 +248,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	const i32 n = (i32)(gend - g0);
 	const u32 qrec = query[groupQuery[g]];
 	const u32 extRec = (u32)(hitKey[g0] >> 32) - P.firstId;
-	const bool extSorted = len[extRec >> 1] > len[qrec >> 1];
+	const bool extSorted = len[extRec >> 1] > qLen[qrec >> 1];
 	const u32* cur = gCur + g0;
 	const u32* ext = gExt + g0;
 	i32* score = gScore + g0;
@@ -346,11 +349,11 @@ template <int CAP, int FIN_WAVES>
 __global__ void __launch_bounds__(FIN_WAVES * 64)
 k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-			   const u32* __restrict__ query, const i32* __restrict__ len, const u64* __restrict__ hitKey,
+			   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
+			   const u64* __restrict__ hitKey,
 			   const u32* __restrict__ gCur, const u32* __restrict__ gExt, i32* __restrict__ gScore,
 			   i32* __restrict__ gBack, u32* __restrict__ gAux /* 4 u32 per hit */, int4* __restrict__ cand,
-			   const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
-			   PrimRec* __restrict__ prim, u32* __restrict__ primFlag)
+			   u32* __restrict__ primCount)
 {
 	constexpr bool USE_LDS = CAP > 0;
 	// dynamic LDS: per wave CAP * 20 bytes (score, back, order key, order value, 2 x u16 scratch)
@@ -400,9 +403,9 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	// the wave screens 64 order entries at once and lane 0 walks only the survivors (re-checking
 	// each, since a chain walked in between may have consumed it).
 	const u32 qrec = query[q];
-	const u32 curId = P.firstId + qrec;
+	const u32 curId = P.qFirstId + qrec;
 	const u32 extId = (u32)(hitKey[g0] >> 32);
-	const i32 curLen = len[qrec >> 1];
+	const i32 curLen = qLen[qrec >> 1];
 	const i32 extLen = len[(extId - P.firstId) >> 1];
 	int4* cd = cand + g0;
 	i32 ncand = 0;
@@ -444,31 +447,44 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	}
 	if (lane != 0) return;
 	if (ncand == 0) return;
+	// candidates in descending score order as std::sort leaves them (overlap.cpp:432-434):
+	// <= 16 elements is a plain (stable) insertion sort, more goes through the emulation
 	if (ncand > 16)
 	{
 		CandAcc acc{cd};
 		fgsort::sort(acc, 0, ncand, stack[wv]);	// 3*40 ints >= fgsort::STACK_INTS
 		best = cd[0];
 	}
-	PrimRec r;
-	r.query = q; r.extId = extId;
-	r.curBegin = (i32)cur[best.x]; r.extBegin = (i32)ext[best.x];
-	r.curEnd = (i32)cur[best.y] + k - 1; r.extEnd = (i32)ext[best.y] + k - 1;
-	r.extLen = extLen; r.score = best.w; r.chainLength = best.z;
+	if (P.onlyMaxExt)
 	{
-		// repetitive query positions inside [curBegin, curEnd] (overlap.cpp:407-413)
-		const i32* fp = filtPos + filtOff[q];
-		const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
-		i32 lo = 0, hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
-		const i32 a = lo;
-		hi = nf;
-		while (lo < hi) { i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
-		r.filtered = lo - a;
+		cd[0] = best;
+		primCount[g] = 1;
+		return;
 	}
-	r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
-	prim[g] = r;
-	primFlag[g] = 1;
+	if (ncand <= 16)
+		for (i32 a = 1; a < ncand; ++a)
+		{
+			const int4 v = cd[a];
+			i32 b = a - 1;
+			while (b >= 0 && cd[b].w < v.w) { cd[b + 1] = cd[b]; --b; }
+			cd[b + 1] = v;
+		}
+	// keep a candidate unless a kept, strictly higher scoring one contains it (overlap.cpp:441-458)
+	i32 nprim = 0;
+	for (i32 a = 0; a < ncand; ++a)
+	{
+		const int4 o = cd[a];
+		const i32 ocb = (i32)cur[o.x], oce = (i32)cur[o.y], oeb = (i32)ext[o.x], oee = (i32)ext[o.y];
+		bool contained = false;
+		for (i32 b = 0; b < nprim && !contained; ++b)
+		{
+			const int4 pr = cd[b];
+			contained = pr.w > o.w && (i32)cur[pr.x] <= ocb && oce <= (i32)cur[pr.y] &&
+						(i32)ext[pr.x] <= oeb && oee <= (i32)ext[pr.y];
+		}
+		if (!contained) cd[nprim++] = o;	// nprim <= a: never overwrites an unread candidate
+	}
+	primCount[g] = (u32)nprim;
 }
 
 u32 fetchU32(fg_ctx* c, const u32* dptr)
@@ -481,8 +497,9 @@ u32 fetchU32(fg_ctx* c, const u32* dptr)
 
 } // namespace
 
-// All target groups of the batch -> prim[g] / dPrimFlag[g] / dDpSize[g]
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, PrimRec* prim)
+// All target groups of the batch -> dPrimFlag[g] = number of primaries (their (first, last,
+// chainLength, score) tuples at the head of the group's dCand region), dDpSize[g]
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits)
 {
 	hipStream_t s = c->stream;
 	ChainParams cp;
@@ -493,8 +510,11 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		cp.minUnique = minKmerSruvivalRate * p->min_overlap;
 	}
 	cp.firstId = c->firstId;
+	cp.qFirstId = c->hasQ ? c->qFirstId : c->firstId;
+	cp.onlyMaxExt = p->only_max_ext ? 1 : 0;
 	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
 	if (!nGroups) return;
+	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
 	// smallest group size that can still have >= minUnique distinct query positions
 	u32 minSize = 0;
 	while ((float)minSize < cp.minUnique) ++minSize;
@@ -514,7 +534,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	if (!nPrep) return;
 	{ ScopedK t(c->timer, "k_group_prep");
 	  hipLaunchKernelGGL(k_group_prep, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
-						 nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p,
+						 nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dHitKey.p,
 						 c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_dp_list");
@@ -530,13 +550,12 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 			{
 				ScopedK t(c->timer, "k_chain_dp");
 				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
-								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, c->dHitKey.p,
+								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dHitKey.p,
 								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
 			}
 	}
 #define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
-		c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dFiltOff.p, c->dFiltPos.p, \
-		prim, c->dPrimFlag.p
+		qLen, c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
 	if (hc[1])
 	{
 		ScopedK t(c->timer, "k_chain_finish<global>");

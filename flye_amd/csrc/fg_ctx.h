@@ -152,6 +152,16 @@ struct fg_ctx {
 	DevBuf<i32> dLen;		// n
 	DevBuf<u64> dKmerOff;	// n+1 prefix of max(len-k,0)
 
+	// optional second container holding the queries (ReadAligner-style use: reads vs graph
+	// edges, reference src/repeat_graph/read_aligner.cpp:178-217); when absent queries are
+	// the indexed reads themselves
+	bool hasQ = false;
+	u32 nQReads = 0, qFirstId = 0;
+	i32 qMaxLen = 0;
+	std::vector<i32> hQLen;
+	DevBuf<u64> dQWords, dQWordOff;
+	DevBuf<i32> dQLen;
+
 	// index
 	bool indexBuilt = false;
 	float sampleRate = 1.0f;
@@ -286,7 +296,7 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, PrimRec* prim);
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,

@@ -126,6 +126,7 @@ __device__ int edit_distance_wave(const u32* __restrict__ A, int n, const u32* _
 
 __global__ void __launch_bounds__(64)
 k_edit_distance(PrimRec* __restrict__ prims, u64 nPrim, const u32* __restrict__ query,
+				const u64* __restrict__ qWords, const u64* __restrict__ qWordOff, const i32* __restrict__ qLen,
 				const u64* __restrict__ words, const u64* __restrict__ wordOff, const i32* __restrict__ len,
 				u32 firstId, int useHpc, int seqWords /* LDS u32 words per string */, int* __restrict__ scratch,
 				u64 scratchPerWave)
@@ -144,7 +145,7 @@ k_edit_distance(PrimRec* __restrict__ prims, u64 nPrim, const u32* __restrict__ 
 		for (int i = lane; i < 2 * seqWords; i += 64) lds[i] = 0;
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		const i32 curRange = r.curEnd - r.curBegin, extRange = r.extEnd - r.extBegin;
-		const int n = extract_seq(words + wordOff[qrec >> 1], len[qrec >> 1], qrec & 1, r.curBegin, curRange, useHpc, A);
+		const int n = extract_seq(qWords + qWordOff[qrec >> 1], qLen[qrec >> 1], qrec & 1, r.curBegin, curRange, useHpc, A);
 		const int m = extract_seq(words + wordOff[erec >> 1], len[erec >> 1], erec & 1, r.extBegin, extRange, useHpc, B);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		const int dist = edit_distance_wave(A, n, B, m, L0, L1);
@@ -165,7 +166,7 @@ void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc)
 {
 	if (!nPrim) return;
 	hipStream_t s = c->stream;
-	const int maxLen = c->maxLen;
+	const int maxLen = std::max(c->maxLen, c->hasQ ? c->qMaxLen : 0);
 	const int seqWords = ((maxLen + 15) / 16 + 4 + 1) & ~1;	// + zero padding for get64
 	const size_t ldsBytes = (size_t)2 * seqWords * 4;
 	if (ldsBytes > 160 * 1024)
@@ -176,6 +177,8 @@ void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc)
 	const u64 perWave = 2 * ((u64)2 * maxLen + 8);
 	c->dEditScratch.reserve((size_t)grid * perWave);
 	ScopedK t(c->timer, "k_edit_distance");
-	hipLaunchKernelGGL(k_edit_distance, grid, 64, ldsBytes, s, dPrims, nPrim, c->dQuery.p, c->dWords.p, c->dWordOff.p,
+	hipLaunchKernelGGL(k_edit_distance, grid, 64, ldsBytes, s, dPrims, nPrim, c->dQuery.p,
+					   c->hasQ ? c->dQWords.p : c->dWords.p, c->hasQ ? c->dQWordOff.p : c->dWordOff.p,
+					   c->hasQ ? c->dQLen.p : c->dLen.p, c->dWords.p, c->dWordOff.p,
 					   c->dLen.p, c->firstId, useHpc, seqWords, c->dEditScratch.p, perWave);
 }

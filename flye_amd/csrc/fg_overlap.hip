@@ -87,6 +87,9 @@ __global__ void k_exscan(const u64* __restrict__ in, u64* __restrict__ out, u32 
 // ---- seed collection ---------------------------------------------------------------
 // per query k-mer: canonicalise, one probe; remember the slot value (+ flip and
 // self-hit flags) so that the fill pass needs no second probe.
+// words/wordOff/len: the QUERY container; kmerOff/indexedBits: the indexed container's k-mer
+// numbering (indexedBits == nullptr when the queries live in their own container: no
+// query can then hit itself)
 __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ words,
 						const u64* __restrict__ wordOff, const i32* __restrict__ len,
 						const u64* __restrict__ kmerOff, const u64* __restrict__ qKmerOff, int k,
@@ -103,7 +106,7 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 	const i32 nk = L - k;
 	const u64* w = words + wordOff[r];
 	u64* pr = probe + qKmerOff[q];
-	const u64 kbase = kmerOff[r];
+	const u64 kbase = indexedBits ? kmerOff[r] : 0;
 	u32 hits = 0, filt = 0;
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
@@ -121,7 +124,7 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 			{
 				// forward position nk (= L-k) is never a forward k-mer position (kmer.h:193-198)
 				const u64 bit = kbase + (u64)qf;
-				const u32 self = qf < nk ? (indexedBits[bit >> 5] >> (bit & 31)) & 1u : 0u;
+				const u32 self = (indexedBits && qf < nk) ? (indexedBits[bit >> 5] >> (bit & 31)) & 1u : 0u;
 				hits += cnt - self;
 				if (self) v |= FLAG_SELF;
 				if (flip) v |= FLAG_FLIP;
@@ -150,7 +153,7 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 // together): key = record << curBits | curPos -- same order, a third less sort traffic;
 // k_expand_keys restores the 64-bit form after the sort.
 template <class KT>
-__global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len,
+__global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
 					   const u64* __restrict__ qKmerOff, int k, u32 firstId, int curBits,
 					   const u64* __restrict__ probe, const u64* __restrict__ entries,
 					   const u64* __restrict__ hitOff, const u64* __restrict__ filtOff,
@@ -162,7 +165,7 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 	__shared__ u32 sSelf[WG];	// index of the trivial self hit inside the list, or 0xFFFFFFFF
 	const u32 q = blockIdx.x;
 	const u32 rec = query[q];
-	const i32 L = len[rec >> 1];
+	const i32 L = qLen[rec >> 1];
 	const i32 nk = L - k;
 	const u64* pr = probe + qKmerOff[q];
 	u64 hbase = hitOff[q];
@@ -407,21 +410,50 @@ __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __rest
 	}
 }
 
-__global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
-							  const PrimRec* __restrict__ prim, const u64* __restrict__ primOff,
-							  PrimRec* __restrict__ out)
+// primaries of every group -> dense PrimRec array in (query, group, selection) order
+__global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __restrict__ primCount,
+							  const u64* __restrict__ groupStart, const u64* __restrict__ hitKey,
+							  const u32* __restrict__ gCur, const u32* __restrict__ gExt, const int4* __restrict__ cand,
+							  const i32* __restrict__ len, u32 firstId, int k,
+							  const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
+							  const u64* __restrict__ primOff, PrimRec* __restrict__ out)
 {
 	__shared__ u32 sh[WG / 64 + 1];
 	const u32 q = blockIdx.x;
 	const u64 b = groupOff[q], e = groupOff[q + 1];
 	u64 obase = primOff[q];
+	const i32* fp = filtPos + filtOff[q];
+	const i32 nf = (i32)(filtOff[q + 1] - filtOff[q]);
 	for (u64 i0 = b; i0 < e; i0 += WG)
 	{
-		const u64 i = i0 + threadIdx.x;
-		const bool f = i < e && primFlag[i];
+		const u64 g = i0 + threadIdx.x;
+		const u32 cnt = g < e ? primCount[g] : 0u;
 		u32 tot;
-		const u32 pos = block_exscan(f ? 1u : 0u, sh, &tot);
-		if (f) out[obase + pos] = prim[i];
+		const u32 pos = block_exscan(cnt, sh, &tot);
+		if (cnt)
+		{
+			const u64 g0 = groupStart[g];
+			const u32 extId = (u32)(hitKey[g0] >> 32);
+			const i32 extLen = len[(extId - firstId) >> 1];
+			for (u32 a = 0; a < cnt; ++a)
+			{
+				const int4 c4 = cand[g0 + a];
+				PrimRec r;
+				r.query = q; r.extId = extId;
+				r.curBegin = (i32)gCur[g0 + c4.x]; r.extBegin = (i32)gExt[g0 + c4.x];
+				r.curEnd = (i32)gCur[g0 + c4.y] + k - 1; r.extEnd = (i32)gExt[g0 + c4.y] + k - 1;
+				r.extLen = extLen; r.score = c4.w; r.chainLength = c4.z;
+				// repetitive query positions inside [curBegin, curEnd] (overlap.cpp:407-413)
+				i32 lo = 0, hi = nf;
+				while (lo < hi) { const i32 m = (lo + hi) >> 1; if (fp[m] < r.curBegin) lo = m + 1; else hi = m; }
+				const i32 first = lo;
+				hi = nf;
+				while (lo < hi) { const i32 m = (lo + hi) >> 1; if (fp[m] <= r.curEnd) lo = m + 1; else hi = m; }
+				r.filtered = lo - first;
+				r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
+				out[obase + pos + a] = r;
+			}
+		}
 		obase += tot;
 	}
 }
@@ -516,10 +548,13 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, hq + qa, nq * 4ULL, hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(c->dQKmerOff.p, localOff.data(), (nq + 1) * 8ULL, hipMemcpyHostToDevice, s));
 
+	const u64* qWords = c->hasQ ? c->dQWords.p : c->dWords.p;
+	const u64* qWordOff = c->hasQ ? c->dQWordOff.p : c->dWordOff.p;
+	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
 	{ ScopedK t(c->timer, "k_probe");
-	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p,
-						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->dIndexedBits.p, c->dProbe.p,
-						 c->dCntA.p, c->dCntB.p); }
+	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,
+						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p,
+						 c->dProbe.p, c->dCntA.p, c->dCntB.p); }
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }
@@ -530,14 +565,14 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
 	// 32-bit sort keys when (record index, query position) fit together
 	int curBits = 1, recBits = 1;
-	while ((1LL << curBits) < (long long)c->maxLen) ++curBits;
+	while ((1LL << curBits) < (long long)(c->hasQ ? c->qMaxLen : c->maxLen)) ++curBits;
 	while ((1ULL << recBits) < 2ULL * c->nReads) ++recBits;
 	const bool key32 = curBits + recBits <= 32 && !getenv("FG_FORCE_KEY64");
 	if (key32)
 	{
 		c->dHitKey32.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
-		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, curBits,
+		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u32>(c, c->dHitOff.p, nq, c->dHitKey32.p, c->dHitVal.p, nHits);
 		if (nHits)
@@ -550,7 +585,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	else
 	{
 		{ ScopedK t(c->timer, "k_fill");
-		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, c->dQKmerOff.p, k, c->firstId, 0,
+		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits);
 	}
@@ -561,13 +596,11 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
 	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "too many target groups in one chunk"};
 	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
-	c->dPrim.reserve((nGroups + 1) * sizeof(PrimRec));
 	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
-	PrimRec* prim = (PrimRec*)c->dPrim.p;
 	{ ScopedK t(c->timer, "k_group_fill");
 	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
 						 c->dGroupQuery.p); }
-	fgChainStage(c, p, forceLocal, nGroups, nHits, prim);
+	fgChainStage(c, p, forceLocal, nGroups, nHits);
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
 						 c->dDpGroups.p, c->dDpElems.p); }
@@ -576,8 +609,9 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
 	c->dPrimOut.reserve((nPrim + 1) * sizeof(PrimRec));
 	{ ScopedK t(c->timer, "k_prim_gather");
-	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, prim, c->dPrimOff.p,
-						 (PrimRec*)c->dPrimOut.p); }
+	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dGroupStart.p, c->dHitKey.p,
+						 c->dCur.p, c->dExt.p, c->dCand.p, c->dLen.p, c->firstId, k, c->dFiltOff.p, c->dFiltPos.p,
+						 c->dPrimOff.p, (PrimRec*)c->dPrimOut.p); }
 	if (p->nucl_alignment) fgEditDistances(c, (PrimRec*)c->dPrimOut.p, nPrim, p->use_hpc);
 	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
 	c->hOff.reserve(3 * (size_t)(nq + 1));
@@ -616,8 +650,8 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	u64 queryBp = 0;
 	for (u32 i = 0; i < nq; ++i)
 	{
-		hq[i] = queryIds[i] - c->firstId;
-		const i32 L = c->hLen[hq[i] >> 1];
+		hq[i] = queryIds[i] - (c->hasQ ? c->qFirstId : c->firstId);
+		const i32 L = (c->hasQ ? c->hQLen : c->hLen)[hq[i] >> 1];
 		hQKmerOff[i + 1] = hQKmerOff[i] + (u64)std::max(0, L - k);
 		queryBp += L;
 	}
@@ -711,7 +745,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		const u32 q0 = (u32)((u64)nq * t / nThreads), q1 = (u32)((u64)nq * (t + 1) / nThreads);
 		for (u32 qi = q0; qi < q1; ++qi)
 		{
-			const i32 curLen = c->hLen[hq[qi] >> 1];
+			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
 			wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
 			size_t detected = 0;
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
@@ -762,7 +796,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		const u32 q0 = (u32)((u64)nq * t / nThreads), q1 = (u32)((u64)nq * (t + 1) / nThreads);
 		for (u32 qi = q0; qi < q1; ++qi)
 		{
-			const i32 curLen = c->hLen[hq[qi] >> 1];
+			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
 			fg_overlap_rec* dst = own->recs + own->queryOff[qi];
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{

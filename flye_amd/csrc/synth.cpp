@@ -93,6 +93,7 @@ struct fs_params {
 	int32_t errPermille10;		// total error rate in 1/10000
 	int32_t subPct, insPct;		// del = 100 - sub - ins
 	int32_t circular;			// sample reads across the genome end
+	uint64_t readSeed;			// != 0: reads are drawn from their own stream (same genome, other reads)
 };
 
 void* fs_create(const fs_params* p)
@@ -146,6 +147,7 @@ void* fs_create(const fs_params* p)
 	}
 
 	// reads
+	if (p->readSeed) rng = Rng(p->readSeed);
 	sim->wordOff.push_back(0);
 	std::vector<uint8_t> buf;
 	while (sim->totalBases < p->targetBases)

@@ -34,7 +34,7 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
                       ("hpc_len_cur", "<i4"), ("hpc_len_ext", "<i4")])
 
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
-               "fg_set_reads", "fg_build_index_solid", "fg_build_index_minimizers",
+               "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
                "fg_kernel_times", "fg_debug_sort_pairs"]
 
@@ -94,6 +94,7 @@ def load_library():
         L.fg_last_error.restype = C.c_char_p
         L.fg_last_error.argtypes = [C.c_void_p]
         L.fg_set_reads.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fg_set_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.fg_build_index_solid.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float,
                                            C.c_float, C.POINTER(IndexStats)]
         L.fg_build_index_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float,
@@ -197,6 +198,12 @@ class Context:
         self.n_reads = rs.n
         self._check(self.L.fg_set_reads(self.h, rs.n, rs.words.ctypes.data, rs.word_off.ctypes.data,
                                         rs.length.ctypes.data, first_seq_id))
+
+    def set_queries(self, rs, first_seq_id):
+        """Second container holding the queries (reads vs graph edges, read_aligner.cpp:178-217)."""
+        self.qrs = rs
+        self._check(self.L.fg_set_queries(self.h, rs.n, rs.words.ctypes.data, rs.word_off.ctypes.data,
+                                          rs.length.ctypes.data, first_seq_id))
 
     def debug_sort_pairs(self, keys, seg_off):
         """Device hit-sort kernel on independent segments; returns (sorted keys, permutation)."""

@@ -21,7 +21,7 @@ class _Params(C.Structure):
                 ("medianLen", C.c_int32), ("sdPermille", C.c_int32),
                 ("minLen", C.c_int32), ("maxLen", C.c_int32),
                 ("errPermille10", C.c_int32), ("subPct", C.c_int32),
-                ("insPct", C.c_int32), ("circular", C.c_int32)]
+                ("insPct", C.c_int32), ("circular", C.c_int32), ("readSeed", C.c_uint64)]
 
 
 def _lib():
@@ -92,10 +92,11 @@ def simulate(seed=12345, genome_len=60_000, coverage=30, kind="pb_raw",
              n_repeat_families=4, repeat_len=(800, 3000), repeat_copies=(2, 5),
              repeat_div_permille=20, n_homopolymers=8, n_tandems=8,
              median_len=None, min_len=None, max_len=None, circular=1,
-             fasta_path=None) -> ReadSet:
+             fasta_path=None, read_seed=0) -> ReadSet:
     """kind: pb_raw (12 % error 15/40/45 sub/ins/del, log-normal sigma .5, median
     ~8.1 kb = e^9), ont_raw (10 % 25/25/50, sigma .8, median ~9.9 kb), hifi
-    (0.5 % error, N(15 kb, 2 kb)) -- the read models of SURVEY.md §8(d)."""
+    (0.5 % error, N(15 kb, 2 kb)) -- the read models of SURVEY.md §8(d).  ``read_seed`` != 0
+    draws the reads from their own stream: same genome (``seed``), different reads."""
     if kind == "pb_raw":
         d = dict(lenModel=0, medianLen=8103, sdPermille=0, minLen=2000, maxLen=40000,
                  errPermille10=1200, subPct=15, insPct=40)
@@ -121,7 +122,7 @@ def simulate(seed=12345, genome_len=60_000, coverage=30, kind="pb_raw",
                 repeatMinCopies=repeat_copies[0], repeatMaxCopies=repeat_copies[1],
                 repeatDivPermille=repeat_div_permille, nHomopolymers=n_homopolymers,
                 nTandems=n_tandems, targetBases=int(genome_len * coverage),
-                circular=circular, **d)
+                circular=circular, readSeed=read_seed, **d)
     lib = _lib()
     h = lib.fs_create(C.byref(p))
     try:

@@ -67,6 +67,16 @@ int fg_set_reads(fg_ctx* ctx, uint32_t n_fwd, const uint64_t* words,
                  const uint64_t* word_off, const int32_t* len,
                  uint32_t first_seq_id);
 
+/* Optional second SequenceContainer holding the QUERIES, for callers whose queries are not
+ * the indexed sequences: ReadAligner::alignReads indexes the graph edge sequences and
+ * queries every read against them (src/repeat_graph/read_aligner.cpp:178-217).  Same
+ * layout as fg_set_reads; the ids must not overlap the indexed container's (the reference
+ * draws both from one process-wide counter, sequence_container.cpp:16, :55-60).  n_fwd = 0
+ * returns to "queries are the indexed reads".  fg_set_reads() also resets it. */
+int fg_set_queries(fg_ctx* ctx, uint32_t n_fwd, const uint64_t* words,
+                   const uint64_t* word_off, const int32_t* len,
+                   uint32_t first_seq_id);
+
 struct fg_index_stats {
 	uint64_t total_kmers;      /* KmerCounter::_numKmers: distinct canonical k-mers
 	                              ("Total k-mers", vertex_index.cpp:589); 0 in
@@ -112,7 +122,8 @@ struct fg_detector_params {
 	int32_t min_overlap;
 	int32_t max_overhang;          /* 0 => _checkOverhang = false */
 	uint8_t keep_alignment;        /* kmerMatches output: FG_ERR_UNSUPPORTED if set */
-	uint8_t only_max_ext;          /* must be 1 for now */
+	uint8_t only_max_ext;          /* 1: best overlap per target (assemble); 0: all primaries
+	                                  not contained in a better one (overlap.cpp:441-458) */
 	uint8_t nucl_alignment;        /* base-level divergence (alignment.cpp:218-247) */
 	uint8_t partition_bad_mappings;/* FG_ERR_UNSUPPORTED if set */
 	uint8_t use_hpc;

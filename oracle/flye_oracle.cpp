@@ -59,6 +59,12 @@ struct Ctx {
 	u32 firstId = 0;
 	std::vector<u64> words, wordOff;
 	std::vector<int32_t> len;
+	// optional second container holding the queries (ReadAligner-style use,
+	// src/repeat_graph/read_aligner.cpp:178-217); ids continue after the indexed ones
+	bool hasQ = false;
+	u32 qn = 0, qFirstId = 0;
+	std::vector<u64> qWords, qWordOff;
+	std::vector<int32_t> qLen;
 	std::vector<u64> recOff;	// 2n+1 global offsets of records (fwd, rc interleaved)
 	Index idx;
 	// last overlap call
@@ -76,11 +82,13 @@ inline u64 mixHash(u64 x)
 }
 
 // sequence.h:120-129 atRaw(), with the lazy reverse-complement flag
-inline u32 baseAt(const Ctx& c, u32 read, int32_t pos, bool rc)
+inline u32 baseAt(const Ctx& c, u32 read, int32_t pos, bool rc, bool fromQ = false)
 {
-	int32_t L = c.len[read];
+	const std::vector<u64>& W = fromQ ? c.qWords : c.words;
+	const u64 w0 = fromQ ? c.qWordOff[read] : c.wordOff[read];
+	int32_t L = fromQ ? c.qLen[read] : c.len[read];
 	int32_t p = rc ? L - 1 - pos : pos;
-	u32 b = (u32)((c.words[c.wordOff[read] + (p >> 5)] >> ((p & 31) * 2)) & 3);
+	u32 b = (u32)((W[w0 + (p >> 5)] >> ((p & 31) * 2)) & 3);
 	return rc ? (~b & 3) : b;
 }
 
@@ -88,23 +96,23 @@ inline u32 baseAt(const Ctx& c, u32 read, int32_t pos, bool rc)
 // last one, at len-k, is never yielded), forward repr (first base most
 // significant), canonical = min(fwd, revcomp), flipped = revcomp < fwd.
 template <class F>
-inline void forEachKmer(const Ctx& c, u32 read, bool rc, F f)
+inline void forEachKmer(const Ctx& c, u32 read, bool rc, F f, bool fromQ = false)
 {
 	const int k = c.k;
-	const int32_t L = c.len[read];
+	const int32_t L = fromQ ? c.qLen[read] : c.len[read];
 	if (L < k) return;
 	const int32_t nk = L - k;
 	const u64 mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
 	u64 fw = 0, rv = 0;
 	for (int i = 0; i < k - 1; ++i)
 	{
-		u64 b = baseAt(c, read, i, rc);
+		u64 b = baseAt(c, read, i, rc, fromQ);
 		fw = (fw << 2) | b;
 		rv = (rv >> 2) | ((3 - b) << (2 * (k - 1)));
 	}
 	for (int32_t p = 0; p < nk; ++p)
 	{
-		u64 b = baseAt(c, read, p + k - 1, rc);
+		u64 b = baseAt(c, read, p + k - 1, rc, fromQ);
 		fw = ((fw << 2) | b) & mask;
 		rv = (rv >> 2) | ((3 - b) << (2 * (k - 1)));
 		f(p, fw, rv);
@@ -330,6 +338,21 @@ int fo_set_reads(fo_ctx* h, u32 n, const u64* words, const u64* wordOff, const i
 	return 0;
 }
 
+// queries from a second container (empty n resets to "queries = indexed reads")
+int fo_set_queries(fo_ctx* h, u32 n, const u64* words, const u64* wordOff, const int32_t* len, u32 firstId)
+{
+	Ctx& c = h->c;
+	c.hasQ = n > 0;
+	c.qn = n; c.qFirstId = firstId;
+	if (n)
+	{
+		c.qWordOff.assign(wordOff, wordOff + n + 1);
+		c.qWords.assign(words, words + wordOff[n]);
+		c.qLen.assign(len, len + n);
+	}
+	return 0;
+}
+
 // countKmers + buildIndexUnevenCoverage (vertex_index.cpp:19-125, :499-590)
 int fo_build_index_solid(fo_ctx* h, int32_t minFreq, float selectRate, int32_t tandemFreq,
 						 float repeatRate, float sampleRateInit, int threads, fg_index_stats* st)
@@ -472,14 +495,15 @@ int fo_export_index(fo_ctx* h, u64* nKeys, u64* nEntries, u64* nRep, u64* keys, 
 namespace {
 
 // alignment.cpp:52-70 homopolymerCompression of seq[start, start+length)
-void extractSeq(const Ctx& c, u32 recIdx, int32_t start, int32_t length, bool hpc, std::vector<uint8_t>& out)
+void extractSeq(const Ctx& c, u32 recIdx, int32_t start, int32_t length, bool hpc, std::vector<uint8_t>& out,
+				bool fromQ = false)
 {
 	out.clear();
 	const u32 read = recIdx >> 1;
 	const bool rc = recIdx & 1;
 	for (int32_t i = 0; i < length; ++i)
 	{
-		uint8_t b = (uint8_t)baseAt(c, read, start + i, rc);
+		uint8_t b = (uint8_t)baseAt(c, read, start + i, rc, fromQ);
 		if (!hpc || i == 0 || out.back() != b) out.push_back(b);
 	}
 }
@@ -572,8 +596,9 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 	const int k = c.k;
 	const u32 read = recIdx >> 1;
 	const bool qrc = recIdx & 1;
-	const int32_t curLen = c.len[read];
-	const u32 curId = c.firstId + recIdx;
+	const bool fromQ = c.hasQ;
+	const int32_t curLen = fromQ ? c.qLen[read] : c.len[read];
+	const u32 curId = (fromQ ? c.qFirstId : c.firstId) + recIdx;
 	const float minKmerSurvivalRate = 0.01;
 	const float LG_GAP = 2, SM_GAP = 0.5;
 	S.hits.clear(); S.filtered.clear();
@@ -591,10 +616,10 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			u32 rec; int32_t pos, len;
 			seqPosition(c, ix.entries[s->off + j], rec, pos, len);
 			if (flip) { rec ^= 1; pos = len - pos - k; }
-			if (rec == recIdx && pos == p) continue;	// no trivial matches
+			if (c.firstId + rec == curId && pos == p) continue;	// no trivial matches
 			S.hits.push_back({p, pos, c.firstId + rec});
 		}
-	});
+	}, fromQ);
 	counters[1] += S.hits.size();
 
 	std::sort(S.hits.begin(), S.hits.end(), [](const Hit& a, const Hit& b)
@@ -749,7 +774,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			if (P.nucl_alignment)
 			{
 				// alignment.cpp:218-247 getAlignmentErrEdlib
-				extractSeq(c, recIdx, o.curBegin, o.curEnd - o.curBegin, P.use_hpc, S.sa);
+				extractSeq(c, recIdx, o.curBegin, o.curEnd - o.curBegin, P.use_hpc, S.sa, fromQ);
 				extractSeq(c, extRec, o.extBegin, o.extEnd - o.extBegin, P.use_hpc, S.sb);
 				int d = editDistance(S.sb, S.sa);
 				r.edit_distance = d;
@@ -780,11 +805,13 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 	int T = std::max(1, threads);
 	std::vector<Scratch> scratch(T);
 	std::vector<std::array<u64, 8>> cnt(T, std::array<u64, 8>{0, 0, 0, 0, 0, 0, 0, 0});
+	const u32 qBase = c.hasQ ? c.qFirstId : c.firstId;
+	const u32 qCount = c.hasQ ? c.qn : c.n;
 	for (u32 i = 0; i < nq; ++i)
-		if (queryIds[i] < c.firstId || queryIds[i] - c.firstId >= 2 * c.n) return FG_ERR_ARG;
+		if (queryIds[i] < qBase || queryIds[i] - qBase >= 2 * qCount) return FG_ERR_ARG;
 	parallelFor(nq, T, [&](u32 i, int t)
 	{
-		seqOverlaps(c, *P, queryIds[i] - c.firstId, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data());
+		seqOverlaps(c, *P, queryIds[i] - qBase, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data());
 	});
 	c.outOff.assign(nq + 1, 0); c.statOff.assign(nq + 1, 0);
 	c.outRecs.clear(); c.outStats.clear();
@@ -794,7 +821,7 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 		c.outOff[i] = c.outRecs.size(); c.statOff[i] = c.outStats.size();
 		c.outRecs.insert(c.outRecs.end(), res[i].begin(), res[i].end());
 		c.outStats.insert(c.outStats.end(), st[i].begin(), st[i].end());
-		c.cntBp += c.len[(queryIds[i] - c.firstId) >> 1];
+		c.cntBp += c.hasQ ? c.qLen[(queryIds[i] - qBase) >> 1] : c.len[(queryIds[i] - qBase) >> 1];
 	}
 	c.outOff[nq] = c.outRecs.size(); c.statOff[nq] = c.outStats.size();
 	c.cntKmers = c.cntHits = c.cntGroups = c.cntDp = 0;

@@ -42,12 +42,15 @@ class DetectorParams(C.Structure):
                 ("pad_", C.c_uint8 * 3), ("max_divergence", C.c_float)]
 
 
-def detector_params(cfg: dict, min_overlap=1000, max_divergence=1.0, only_max_ext=True):
-    """OverlapDetector ctor arguments as main_assemble.cpp:229-238 passes them."""
+def detector_params(cfg: dict, min_overlap=1000, max_divergence=1.0, only_max_ext=True, max_overhang=None,
+                    nucl_alignment=None):
+    """OverlapDetector ctor arguments as main_assemble.cpp:229-238 passes them (or, with the
+    overrides, as read_aligner.cpp:186-192 does)."""
     return DetectorParams(max_jump=int(cfg["maximum_jump"]), min_overlap=int(min_overlap),
-                          max_overhang=int(cfg["maximum_overhang"]), keep_alignment=0,
-                          only_max_ext=int(only_max_ext),
-                          nucl_alignment=int(bool(cfg["reads_base_alignment"])),
+                          max_overhang=int(cfg["maximum_overhang"] if max_overhang is None else max_overhang),
+                          keep_alignment=0, only_max_ext=int(only_max_ext),
+                          nucl_alignment=int(bool(cfg["reads_base_alignment"]) if nucl_alignment is None
+                                             else bool(nucl_alignment)),
                           partition_bad_mappings=0, use_hpc=int(bool(cfg["hpc_scoring_on"])),
                           max_divergence=float(max_divergence))
 
@@ -66,6 +69,7 @@ def lib():
         L.fo_create.argtypes = [C.c_int]
         L.fo_destroy.argtypes = [C.c_void_p]
         L.fo_set_reads.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fo_set_queries.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.fo_build_index_solid.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float,
                                            C.c_float, C.c_int, C.POINTER(IndexStats)]
         L.fo_build_index_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int,
@@ -162,6 +166,13 @@ class Oracle:
                                  rs.length.ctypes.data, first_seq_id)
         assert rc == 0
 
+    def set_queries(self, rs, first_seq_id):
+        """Second container holding the queries (ReadAligner-style)."""
+        self.qrs = rs
+        rc = self.L.fo_set_queries(self.h, rs.n, rs.words.ctypes.data, rs.word_off.ctypes.data,
+                                   rs.length.ctypes.data, first_seq_id)
+        assert rc == 0
+
     def build_index_solid(self, min_freq, select_rate, tandem_freq, repeat_rate, sample_rate_init=1.0):
         st = IndexStats()
         rc = self.L.fo_build_index_solid(self.h, min_freq, select_rate, tandem_freq, repeat_rate,
@@ -244,7 +255,8 @@ def have_ref() -> bool:
 
 def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, max_overlaps=0,
             force_local=False, min_overlap=1000, div_mode="none", index_out=None, ovlp_out=None,
-            query_limit=None, rc_queries=False):
+            query_limit=None, rc_queries=False, queries_fasta=None, only_max=None, max_overhang=None,
+            nucl_aln=None):
     cmd = [REF_DUMPER, "--reads", fasta, "--threads", str(threads), "--min-read-len", str(min_read_len),
            "--max-overlaps", str(max_overlaps), "--force-local", str(int(force_local)),
            "--min-overlap", str(min_overlap), "--div-mode", div_mode]
@@ -260,6 +272,14 @@ def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, m
         cmd += ["--query-limit", str(query_limit)]
     if rc_queries:
         cmd += ["--rc-queries"]
+    if queries_fasta:
+        cmd += ["--queries", queries_fasta]
+    if only_max is not None:
+        cmd += ["--only-max", str(int(only_max))]
+    if max_overhang is not None:
+        cmd += ["--max-overhang", str(int(max_overhang))]
+    if nucl_aln is not None:
+        cmd += ["--nucl-aln", str(int(nucl_aln))]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True)
     return json.loads(out.stdout.strip().splitlines()[-1])
 

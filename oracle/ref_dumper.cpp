@@ -51,7 +51,8 @@ static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 int main(int argc, char** argv)
 {
-	std::string reads, params, config, indexOut, ovlpOut, divMode = "none";
+	std::string reads, queriesFile, params, config, indexOut, ovlpOut, divMode = "none";
+	int onlyMax = 1, maxOverhang = -1, nuclAln = -1;
 	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
 	int minOverlap = 1000;	// main_assemble.cpp:174
 	long queryLimit = -1;
@@ -73,6 +74,10 @@ int main(int argc, char** argv)
 		else if (a == "--ovlp-out") ovlpOut = next();
 		else if (a == "--query-limit") queryLimit = atol(next().c_str());
 		else if (a == "--rc-queries") rcQueries = true;
+		else if (a == "--queries") queriesFile = next();	// second container (ReadAligner-style)
+		else if (a == "--only-max") onlyMax = atoi(next().c_str());
+		else if (a == "--max-overhang") maxOverhang = atoi(next().c_str());
+		else if (a == "--nucl-aln") nuclAln = atoi(next().c_str());
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	if (!config.empty()) Config::load(config);
@@ -139,16 +144,26 @@ int main(int argc, char** argv)
 		fclose(f);
 	}
 
+	// optional second container: queries differ from the indexed sequences, as in
+	// ReadAligner::alignReads (src/repeat_graph/read_aligner.cpp:178-217); its ids
+	// continue after the first container's (process-global g_nextSeqId)
+	SequenceContainer queryContainer;
+	if (!queriesFile.empty())
+	{
+		queryContainer.loadFromFile(queriesFile, minReadLen);
+		queryContainer.buildPositionIndex();
+	}
+	const SequenceContainer& qc = queriesFile.empty() ? readsContainer : queryContainer;
 	OverlapDetector ovlp(readsContainer, vertexIndex,
 						 (int)Config::get("maximum_jump"),
 						 Parameters::get().minimumOverlap,
-						 (int)Config::get("maximum_overhang"),
-						 /*store alignment*/ false, /*only max*/ true,
+						 maxOverhang >= 0 ? maxOverhang : (int)Config::get("maximum_overhang"),
+						 /*store alignment*/ false, /*only max*/ (bool)onlyMax,
 						 /*no div threshold*/ 1.0f,
-						 (bool)Config::get("reads_base_alignment"),
+						 nuclAln >= 0 ? (bool)nuclAln : (bool)Config::get("reads_base_alignment"),
 						 /*partition bad*/ false,
 						 (bool)Config::get("hpc_scoring_on"));
-	OverlapContainer readOverlaps(ovlp, readsContainer);
+	OverlapContainer readOverlaps(ovlp, qc);
 	float meanDiv = 0.0f;
 	if (divMode == "assemble")
 	{
@@ -161,7 +176,7 @@ int main(int argc, char** argv)
 	auto t3 = clk::now();
 
 	std::vector<FastaRecord::Id> queries;
-	for (const auto& seq : readsContainer.iterSeqs())
+	for (const auto& seq : qc.iterSeqs())
 	{
 		if (seq.id.strand() != rcQueries) queries.push_back(seq.id);
 		if (queryLimit >= 0 && (long)queries.size() >= queryLimit) break;
@@ -174,7 +189,7 @@ int main(int argc, char** argv)
 	[&](const FastaRecord::Id& id)
 	{
 		results[slot[id._id]] = readOverlaps.quickSeqOverlaps(id, maxOverlaps, forceLocal);
-		queriedBp += readsContainer.seqLen(id);
+		queriedBp += qc.seqLen(id);
 	};
 	processInParallel(queries, work, threads, false);
 	auto t4 = clk::now();

@@ -45,6 +45,19 @@ CASES = [
          min_read_len=1000, force_local=True),
     dict(name="hifi_rc_max", preset="hifi", sim=dict(seed=107, genome_len=50_000, coverage=25, kind="hifi03"),
          min_read_len=1000, rc_queries=True, max_overlaps=20),
+    # ReadAligner-style use (src/repeat_graph/read_aligner.cpp:178-217): index = long "edge"
+    # sequences, queries = reads from a second container, all primaries (onlyMax = false),
+    # minOverlap = 100, no overhang check, k-mer divergence only
+    dict(name="edges_raw", preset="raw",
+         sim=dict(seed=108, genome_len=60_000, coverage=3, kind="hifi03", median_len=20000, min_len=8000,
+                  max_len=30000, read_seed=7),
+         queries_sim=dict(seed=108, genome_len=60_000, coverage=12, kind="pb_raw", read_seed=9),
+         min_read_len=0, min_overlap=100, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True),
+    dict(name="edges_hifi", preset="hifi",
+         sim=dict(seed=109, genome_len=60_000, coverage=3, kind="hifi03", median_len=20000, min_len=8000,
+                  max_len=30000, read_seed=7, n_repeat_families=8),
+         queries_sim=dict(seed=109, genome_len=60_000, coverage=10, kind="hifi", read_seed=9, n_repeat_families=8),
+         min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True),
 ]
 
 
@@ -67,12 +80,22 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             fa = os.path.join(tmp, "reads.fasta")
             rs = synth.simulate(fasta_path=fa, **case["sim"]).filter_min_len(case["min_read_len"])
-            info = O.run_ref(fa, config=CFG_DIR + config.CFG_FILES[case["preset"]], threads=8,
+            extra = {}
+            params = None
+            if "queries_sim" in case:
+                qfa = os.path.join(tmp, "queries.fasta")
+                synth.simulate(fasta_path=qfa, **case["queries_sim"])
+                cfgd = config.preset(case["preset"])
+                wnd = int(cfgd["minimizer_window"]) if cfgd["use_minimizers"] else 1
+                params = f"use_minimizers=1,minimizer_window={wnd}"     # read_aligner.cpp:180-182
+                extra = dict(queries_fasta=qfa, only_max=case["only_max"], max_overhang=case["max_overhang"],
+                             nucl_aln=case["nucl_aln"], min_overlap=case["min_overlap"])
+            info = O.run_ref(fa, config=CFG_DIR + config.CFG_FILES[case["preset"]], params_string=params, threads=8,
                              min_read_len=case["min_read_len"], max_overlaps=case.get("max_overlaps", 0),
                              force_local=case.get("force_local", False),
                              div_mode=case.get("div_mode", "none"),
                              index_out=os.path.join(tmp, "index.txt"), ovlp_out=os.path.join(tmp, "ovlp.txt"),
-                             rc_queries=case.get("rc_queries", False))
+                             rc_queries=case.get("rc_queries", False), **extra)
             hdr, ix = O.parse_ref_index(os.path.join(tmp, "index.txt"), rs)
             lines = open(os.path.join(tmp, "ovlp.txt")).read()
             first = lines.split("\n", 1)[0].split()

@@ -41,3 +41,16 @@ def check_index_stats(st, gold):
     for f in ("total_kmers", "selected_kmers", "index_entries", "repetitive_kmers", "repetitive_frequency"):
         assert int(st[f]) == int(gold[f]), (f, st[f], gold[f])
     assert np.float32(st["sample_rate"]).view(np.uint32) == int(gold["sample_rate_bits"], 16)
+
+
+def golden_queries(case):
+    """Second container of a ReadAligner-style case (ids continue after the indexed ones)."""
+    from flye_amd import synth
+    return synth.simulate(**case["queries_sim"])
+
+
+def edges_setup(case, cfg):
+    """(window, detector kwargs) of a ReadAligner-style golden case."""
+    wnd = int(cfg["minimizer_window"]) if cfg["use_minimizers"] else 1
+    return wnd, dict(min_overlap=case["min_overlap"], only_max_ext=bool(case["only_max"]),
+                     max_overhang=case["max_overhang"], nucl_alignment=case["nucl_aln"])

@@ -106,6 +106,54 @@ def test_against_oracle_variants(built, seed, kind, opts):
         assert a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi"])
+def test_read_aligner_style_golden(built, golden_cases, name):
+    """fg_set_queries + only_max_ext = 0: reads from a second container against an index of
+    "edge" sequences, every primary overlap (ReadAligner::alignReads flags,
+    read_aligner.cpp:178-217), vs the reference's golden output and the oracle."""
+    from flye_amd import config, gpu
+    from oracle import oracle as O
+    from helpers import edges_setup, golden_queries
+    case = golden_cases[name]
+    edges = golden_reads(case)
+    reads = golden_queries(case)
+    cfg = config.preset(case["preset"])
+    wnd, dk = edges_setup(case, cfg)
+    ctx = gpu.Context(int(cfg["kmer_size"]), 0)
+    ctx.set_reads(edges, 0)
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    st = vi.buildIndexMinimizers(1, wnd, cfg["repeat_kmer_rate"])
+    check_index_stats(st, case["index"])
+    assert index_digest(vi.export()) == case["index"]["sha256"]
+    ctx.set_queries(reads, 2 * edges.n)
+    det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], False,
+                              dk["only_max_ext"], 1.0, dk["nucl_alignment"], False, bool(cfg["hpc_scoring_on"]))
+    q = (2 * edges.n + np.arange(0, 2 * reads.n)).astype(np.uint32)      # both strands
+    res = det.getSeqOverlapsBatch(q)
+    fwd = res.query_ids % 2 == 0
+    lines = res.lines()
+    got = [l for i in np.nonzero(fwd)[0] for l in lines[int(res.query_off[i]):int(res.query_off[i + 1])]]
+    assert got == golden_lines(name)
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(edges, 0)
+    o.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
+    o.set_queries(reads, 2 * edges.n)
+    ores = o.overlaps(O.detector_params(cfg, **dk), q)
+    assert lines == ores.lines()
+    assert np.array_equal(res.stats.view(np.uint32), ores.stats.view(np.uint32))
+    # ids of the query container are rejected when they collide with the indexed ones
+    with pytest.raises(gpu.FlyeGpuError):
+        ctx.set_queries(reads, 2 * edges.n - 2)
+    # back to "queries are the indexed reads"
+    ctx.set_reads(edges, 0)
+    vi.buildIndexMinimizers(1, wnd, cfg["repeat_kmer_rate"])
+    self_res = det.getSeqOverlapsBatch(np.arange(0, 2 * edges.n, 2, dtype=np.uint32))
+    o2 = O.Oracle(int(cfg["kmer_size"]))
+    o2.set_reads(edges, 0)
+    o2.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
+    assert self_res.lines() == o2.overlaps(O.detector_params(cfg, **dk), np.arange(0, 2 * edges.n, 2)).lines()
+
+
 def _median3_killer(n):
     k = n // 2
     a = np.zeros(n, np.uint64)

@@ -25,3 +25,28 @@ def test_oracle_matches_reference_golden(built, golden_cases, name):
                      force_local=case.get("force_local", False))
     assert res.lines() == golden_lines(name)
     assert len(res.recs) == case["n_overlaps"]
+
+
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi"])
+def test_oracle_read_aligner_style_golden(built, golden_cases, name):
+    """Queries from a second container against an index of other sequences, all primaries
+    (ReadAligner::alignReads flags), vs the reference's output."""
+    import numpy as np
+    from flye_amd import config
+    from oracle import oracle as O
+    from helpers import edges_setup, golden_queries
+    case = golden_cases[name]
+    edges = golden_reads(case)
+    reads = golden_queries(case)
+    cfg = config.preset(case["preset"])
+    wnd, dk = edges_setup(case, cfg)
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(edges, 0)
+    st = o.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
+    check_index_stats(st, case["index"])
+    assert index_digest(o.export_index()) == case["index"]["sha256"]
+    o.set_queries(reads, 2 * edges.n)
+    q = 2 * edges.n + np.arange(0, 2 * reads.n, 2)
+    res = o.overlaps(O.detector_params(cfg, **dk), q)
+    assert res.lines() == golden_lines(name)
+    assert len(res.recs) == case["n_overlaps"] > 0
