@@ -56,3 +56,36 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for pat in (r"import\s+oracle", r"from\s+oracle", r"liboracle", r"oracle/", r"fo_[a-z_]+\("):
                     assert not re.search(pat, src), f"{f} reaches into the test oracle ({pat})"
+
+
+def _build_c_demo(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_demo")
+    lib = os.path.join(ROOT, "flye_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + lib, "-lflyegpu",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_links(built, tmp_path):
+    """include/flye_gpu.h compiles as C99 and a C program links against the library; without
+    a GPU the program reports FG_ERR_NO_DEVICE (exit status 2)."""
+    import subprocess
+    import torch
+    exe = _build_c_demo(tmp_path)
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no usable HIP device" in r.stdout
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_c_consumer_runs_on_gpu(built, tmp_path):
+    import subprocess
+    exe = _build_c_demo(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "overlaps for 60 reads" in r.stdout
