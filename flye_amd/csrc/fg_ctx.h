@@ -183,7 +183,7 @@ struct fg_ctx {
 	DevBuf<u64> dHitKey;		// extId<<32 | curPos
 	DevBuf<u32> dHitVal;		// extPos
 	DevBuf<u32> dHitKey32;		// record << curBits | curPos, when that fits 32 bits (sort only)
-	DevBuf<i32> dScore, dBack, dOrder;
+	DevBuf<i32> dScore, dBack;
 	DevBuf<int4> dCand;
 	DevBuf<u64> dGroupStart;	// group boundaries (indices into hits)
 	DevBuf<u32> dGroupQuery;
@@ -191,7 +191,7 @@ struct fg_ctx {
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
 	DevBuf<u32> dCur, dExt;		// (cur, ext) columns of the groups in DP order
-	DevBuf<char> dPrim, dPrimOut;	// PrimRec arrays
+	DevBuf<char> dPrimOut;	// PrimRec array
 	DevBuf<char> dSortTasks, dSortBig;
 	DevBuf<int> dEditScratch;
 	PinnedBuf<char> hPrim;

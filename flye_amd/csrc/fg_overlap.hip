@@ -748,12 +748,18 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
 			wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
 			size_t detected = 0;
+			u32 prevExt = 0xFFFFFFFFu;
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
-				// groups are visited in ascending extId; the limit is tested at each group
-				// start against the overlaps accepted so far (overlap.cpp:218-219)
-				if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
 				const PrimRec& r = hPrim[j];
+				// groups are visited in ascending extId; the limit is tested only at a group
+				// start, against the overlaps accepted so far (overlap.cpp:218-219) -- a group
+				// with several primaries (onlyMaxExt = false) is never cut in the middle
+				if (r.extId != prevExt)
+				{
+					if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
+					prevExt = r.extId;
+				}
 				// overlap.cpp:414-423
 				float normLen = std::max(r.curEnd - r.curBegin, r.extEnd - r.extBegin) - r.filtered;
 				float matchRate = (float)r.chainLength * sampleRate / normLen;

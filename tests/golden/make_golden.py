@@ -53,6 +53,12 @@ CASES = [
                   max_len=30000, read_seed=7),
          queries_sim=dict(seed=108, genome_len=60_000, coverage=12, kind="pb_raw", read_seed=9),
          min_read_len=0, min_overlap=100, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True),
+    dict(name="edges_raw_max", preset="raw",
+         sim=dict(seed=110, genome_len=50_000, coverage=4, kind="hifi03", median_len=12000, min_len=5000,
+                  max_len=30000, read_seed=7, n_repeat_families=10),
+         queries_sim=dict(seed=110, genome_len=50_000, coverage=10, kind="ont_raw", read_seed=9, n_repeat_families=10),
+         min_read_len=0, min_overlap=100, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True,
+         max_overlaps=4),
     dict(name="edges_hifi", preset="hifi",
          sim=dict(seed=109, genome_len=60_000, coverage=3, kind="hifi03", median_len=20000, min_len=8000,
                   max_len=30000, read_seed=7, n_repeat_families=8),

@@ -61,6 +61,8 @@ def test_golden_reference_vectors(built, golden_cases, name):
     (5, "hifi", dict(preset="hifi", mixed=True, max_div=0.01, cov=20)),
     (6, "hifi03", dict(preset="corrected", max_overlaps=9, hp=60, tr=60, cov=20)),
     (7, "pb_raw", dict(preset="hifi", cov=20)),     # divergent pairs through the edit-distance kernel
+    (8, "pb_raw", dict(all_primaries=True, max_overlaps=5, mixed=True)),   # limit is tested per target group
+    (9, "hifi", dict(preset="corrected", all_primaries=True, max_overlaps=3, cov=15, rep=10)),
 ])
 def test_against_oracle_variants(built, seed, kind, opts):
     from flye_amd import config, gpu, synth
@@ -76,6 +78,7 @@ def test_against_oracle_variants(built, seed, kind, opts):
     gst = vi.build(cfg)
     det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
     det.p.max_divergence = opts.get("max_div", 1.0)
+    det.p.only_max_ext = 0 if opts.get("all_primaries") else 1
     o = O.Oracle(17)
     o.set_reads(rs, first)
     ost = o.build_index(cfg)
@@ -86,7 +89,8 @@ def test_against_oracle_variants(built, seed, kind, opts):
     q = q.astype(np.uint32)
     gres = det.getSeqOverlapsBatch(q, forceLocal=opts.get("force_local", False),
                                    maxOverlaps=opts.get("max_overlaps", 0))
-    ores = o.overlaps(O.detector_params(cfg, max_divergence=opts.get("max_div", 1.0)), q,
+    ores = o.overlaps(O.detector_params(cfg, max_divergence=opts.get("max_div", 1.0),
+                                        only_max_ext=not opts.get("all_primaries")), q,
                       max_overlaps=opts.get("max_overlaps", 0), force_local=opts.get("force_local", False))
     assert gres.lines() == ores.lines()
     assert np.array_equal(gres.query_off, ores.query_off)
@@ -106,7 +110,7 @@ def test_against_oracle_variants(built, seed, kind, opts):
         assert a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi"])
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max"])
 def test_read_aligner_style_golden(built, golden_cases, name):
     """fg_set_queries + only_max_ext = 0: reads from a second container against an index of
     "edge" sequences, every primary overlap (ReadAligner::alignReads flags,
@@ -129,7 +133,8 @@ def test_read_aligner_style_golden(built, golden_cases, name):
     det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], False,
                               dk["only_max_ext"], 1.0, dk["nucl_alignment"], False, bool(cfg["hpc_scoring_on"]))
     q = (2 * edges.n + np.arange(0, 2 * reads.n)).astype(np.uint32)      # both strands
-    res = det.getSeqOverlapsBatch(q)
+    mo = case.get("max_overlaps", 0)
+    res = det.getSeqOverlapsBatch(q, maxOverlaps=mo)
     fwd = res.query_ids % 2 == 0
     lines = res.lines()
     got = [l for i in np.nonzero(fwd)[0] for l in lines[int(res.query_off[i]):int(res.query_off[i + 1])]]
@@ -138,7 +143,7 @@ def test_read_aligner_style_golden(built, golden_cases, name):
     o.set_reads(edges, 0)
     o.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
     o.set_queries(reads, 2 * edges.n)
-    ores = o.overlaps(O.detector_params(cfg, **dk), q)
+    ores = o.overlaps(O.detector_params(cfg, **dk), q, max_overlaps=mo)
     assert lines == ores.lines()
     assert np.array_equal(res.stats.view(np.uint32), ores.stats.view(np.uint32))
     # ids of the query container are rejected when they collide with the indexed ones
@@ -357,3 +362,15 @@ def test_full_size_properties(built):
         got += [f"{p['cur_id']} {p['cur_begin']} {p['cur_end']} {p['cur_len']} {p['ext_id']} {p['ext_begin']} "
                 f"{p['ext_end']} {p['ext_len']} {p['score']} {bits[j]:08x}" for j, p in enumerate(part)]
     assert got == want
+
+
+def test_randomised_parity_sweep(built):
+    """A fixed-seed slice of tools/fuzz_parity.py: random read models, presets, k, windows,
+    detector flags and query mixes; index and every overlap record must equal the oracle's."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed=5, n_cases=10, verbose=False) == 0

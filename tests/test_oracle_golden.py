@@ -27,7 +27,7 @@ def test_oracle_matches_reference_golden(built, golden_cases, name):
     assert len(res.recs) == case["n_overlaps"]
 
 
-@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi"])
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max"])
 def test_oracle_read_aligner_style_golden(built, golden_cases, name):
     """Queries from a second container against an index of other sequences, all primaries
     (ReadAligner::alignReads flags), vs the reference's output."""
@@ -47,6 +47,6 @@ def test_oracle_read_aligner_style_golden(built, golden_cases, name):
     assert index_digest(o.export_index()) == case["index"]["sha256"]
     o.set_queries(reads, 2 * edges.n)
     q = 2 * edges.n + np.arange(0, 2 * reads.n, 2)
-    res = o.overlaps(O.detector_params(cfg, **dk), q)
+    res = o.overlaps(O.detector_params(cfg, **dk), q, max_overlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
     assert len(res.recs) == case["n_overlaps"] > 0
