@@ -282,6 +282,19 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 		const i32 cn = __builtin_amdgcn_readlane(tc, il), en = __builtin_amdgcn_readlane(te, il);
 		i32 maxScore = 0, maxId = 0;
 		bool done = false;
+		{
+			// scalar fast path: the predecessor i-1 lies on the same diagonal less than k ahead.
+			// It is the first candidate of the scan, improves on 0 (its score is >= 0) and
+			// triggers the reference's early exit at once (overlap.cpp:301-307).
+			const i32 c0 = __builtin_amdgcn_readlane(wc, 0), e0 = __builtin_amdgcn_readlane(we, 0);
+			const i32 dc0 = cn - c0;
+			if (dc0 == en - e0 && dc0 > 0 && dc0 < k && dc0 < maxJump)
+			{
+				maxScore = __builtin_amdgcn_readlane(ws, 0) + dc0;
+				maxId = i - 1;
+				done = true;
+			}
+		}
 		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
 		{
 			const i32 j = jb - lane;
