@@ -111,6 +111,7 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 }
 
 #define FIN_CAP_S 256		// <= : LDS, 4 groups per block; larger groups run on global scratch.
+#define FIN_BT_CAP 0	// > 0: global-scratch groups up to this size backtrack in LDS (measured slower: occupancy)
 // (Measured: staging 257..1024-hit groups in LDS at 2 waves per block, or > 2048-hit groups at
 // one wave per block, is slower than global scratch -- the occupancy lost costs more than the
 // latency saved.)
@@ -358,7 +359,8 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 
 // ---- finish ------------------------------------------------------------------------------
 // CAP = 0: everything in global scratch; otherwise the group (<= CAP hits) is staged in LDS
-template <int CAP, int FIN_WAVES>
+// BT_CAP > 0 (CAP = 0 only): groups of <= BT_CAP hits walk their back pointers in LDS
+template <int CAP, int FIN_WAVES, int BT_CAP = 0>
 __global__ void __launch_bounds__(FIN_WAVES * 64)
 k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
@@ -373,6 +375,7 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	extern __shared__ __attribute__((aligned(16))) char finLds[];
 	__shared__ int stack[FIN_WAVES][3 * 40];
 	__shared__ int small[FIN_WAVES][3 * 8];
+	__shared__ i32 btLds[FIN_WAVES][BT_CAP > 0 ? BT_CAP : 1];
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
 	const u32 li = blockIdx.x * FIN_WAVES + wv;
@@ -411,6 +414,12 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	}
 
 	if (P.ablate & 8) return;
+	if (BT_CAP > 0 && n <= BT_CAP)
+	{
+		// the serial pointer chase below is latency bound: keep the back pointers in LDS
+		for (i32 i = lane; i < n; i += 64) btLds[wv][i] = back[i];
+		back = btLds[wv];
+	}
 	// backtracking with consumption, overlapTest, primary selection.  Consumption only ever
 	// turns back[] entries into -1, so a start whose entry already is -1 can be skipped for good:
 	// the wave screens 64 order entries at once and lane 0 walks only the survivors (re-checking
@@ -572,7 +581,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	if (hc[1])
 	{
 		ScopedK t(c->timer, "k_chain_finish<global>");
-		hipLaunchKernelGGL((k_chain_finish<0, 4>), (hc[1] + 3) / 4, 256, 0, s, FIN_ARGS(1));
+		hipLaunchKernelGGL((k_chain_finish<0, 4, FIN_BT_CAP>), (hc[1] + 3) / 4, 256, 0, s, FIN_ARGS(1));
 	}
 	if (hc[0])
 	{
