@@ -27,6 +27,7 @@ struct ChainParams {
 	u32 firstId;		// FastaRecord id of the first indexed record
 	u32 qFirstId;		// ... of the first query record (= firstId unless a query container is set)
 	int onlyMaxExt;
+	int keepAln;		// the DP's back pointers must survive the backtracking (k_chain_matches re-walks them)
 	int ablate;			// timing experiments only (FG_ABLATE env; results become wrong)
 };
 
@@ -414,6 +415,13 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	}
 
 	if (P.ablate & 8) return;
+	if (!USE_LDS && P.keepAln)
+	{
+		// consume a copy (the sort's position scratch is free now), keep gBack intact
+		i32* bc = (i32*)(oval + n);
+		for (i32 i = lane; i < n; i += 64) bc[i] = back[i];
+		back = bc;
+	}
 	if (BT_CAP > 0 && n <= BT_CAP)
 	{
 		// the serial pointer chase below is latency bound: keep the back pointers in LDS
@@ -534,6 +542,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	cp.firstId = c->firstId;
 	cp.qFirstId = c->hasQ ? c->qFirstId : c->firstId;
 	cp.onlyMaxExt = p->only_max_ext ? 1 : 0;
+	cp.keepAln = p->keep_alignment ? 1 : 0;
 	cp.ablate = getenv("FG_ABLATE") ? atoi(getenv("FG_ABLATE")) : 0;
 	if (!nGroups) return;
 	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;

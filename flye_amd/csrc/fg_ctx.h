@@ -192,6 +192,12 @@ struct fg_ctx {
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
 	DevBuf<u32> dCur, dExt;		// (cur, ext) columns of the groups in DP order
 	DevBuf<char> dPrimOut;	// PrimRec array
+	// keep_alignment: per primary the chain's last hit (global hit index), its group's first
+	// hit, the slot offsets (chainLength + 2 pairs each) and the thinned chain itself
+	DevBuf<u64> dPrimNode, dPrimBase, dMatchSize, dMatchOff, dMatches;
+	DevBuf<u32> dMatchCnt;
+	PinnedBuf<u64> hMatches, hMatchOff;
+	PinnedBuf<u32> hMatchCnt;
 	DevBuf<char> dSortTasks, dSortBig;
 	DevBuf<int> dEditScratch;
 	PinnedBuf<char> hPrim;
@@ -271,6 +277,17 @@ struct BatchOwner {
 	fg_overlap_rec* recs = nullptr;
 	size_t recCap = 0, nRecs = 0;
 	std::vector<float> stats;
+	std::vector<u64> matchOff;	// keep_alignment: nRecs + 1, in pairs
+	int32_t* matches = nullptr;	// (cur, ext) pairs
+	size_t matchCap = 0;
+	void reserveMatches(size_t nPairs)
+	{
+		if (nPairs <= matchCap) return;
+		free(matches);
+		matchCap = nPairs + nPairs / 8 + 16;
+		matches = (int32_t*)malloc(matchCap * 8);
+		if (!matches) { matchCap = 0; throw std::bad_alloc(); }
+	}
 	void reserveRecs(size_t n)
 	{
 		if (n <= recCap) return;
@@ -279,7 +296,7 @@ struct BatchOwner {
 		recs = (fg_overlap_rec*)malloc(recCap * sizeof(fg_overlap_rec));
 		if (!recs) { recCap = 0; throw std::bad_alloc(); }
 	}
-	~BatchOwner() { free(recs); }
+	~BatchOwner() { free(recs); free(matches); }
 	static BatchOwner* acquire();
 	static void release(BatchOwner* b);
 };

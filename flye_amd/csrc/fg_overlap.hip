@@ -416,7 +416,8 @@ __global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __res
 							  const u32* __restrict__ gCur, const u32* __restrict__ gExt, const int4* __restrict__ cand,
 							  const i32* __restrict__ len, u32 firstId, int k,
 							  const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
-							  const u64* __restrict__ primOff, PrimRec* __restrict__ out)
+							  const u64* __restrict__ primOff, PrimRec* __restrict__ out,
+							  u64* __restrict__ primNode, u64* __restrict__ primBase, u64* __restrict__ matchSize)
 {
 	__shared__ u32 sh[WG / 64 + 1];
 	const u32 q = blockIdx.x;
@@ -452,10 +453,51 @@ __global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __res
 				r.filtered = lo - first;
 				r.editDistance = -1; r.hpcLenCur = 0; r.hpcLenExt = 0;
 				out[obase + pos + a] = r;
+				if (primNode)	// keep_alignment
+				{
+					primNode[obase + pos + a] = g0 + (u64)c4.y;
+					primBase[obase + pos + a] = g0;
+					matchSize[obase + pos + a] = (u64)c4.z + 2;
+				}
 			}
 		}
 		obase += tot;
 	}
+}
+
+// kmerMatches of every primary (overlap.cpp:368-377, 398-405): the chain is walked again from
+// its last hit along the DP's back pointers (chainLength nodes -- where the consuming walk of
+// k_chain_finish stopped), keeping a match when it lies > k query bases before the last kept
+// one; then (curBegin, extBegin) in front and (curEnd, extEnd) behind.  One thread per
+// primary; the list is written right-aligned into the primary's slot of chainLength + 2 pairs.
+__global__ void k_chain_matches(const PrimRec* __restrict__ prims, u64 nPrim, const u64* __restrict__ primNode,
+								const u64* __restrict__ primBase, const u64* __restrict__ matchOff,
+								const u32* __restrict__ gCur, const u32* __restrict__ gExt,
+								const i32* __restrict__ gBack, int k, u64* __restrict__ matches,
+								u32* __restrict__ matchCnt)
+{
+	const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= nPrim) return;
+	const PrimRec r = prims[p];
+	const u64 base = primBase[p];
+	u64* slot = matches + matchOff[p];
+	const i32 ub = r.chainLength + 2;
+	i32 pos = (i32)(primNode[p] - base);
+	i32 kept = 0, lastCur = 0;
+	for (i32 step = 0; step < r.chainLength; ++step)
+	{
+		const i32 cu = (i32)gCur[base + pos];
+		if (kept == 0 || lastCur - cu > k)
+		{
+			slot[ub - 2 - kept] = (u64)(u32)cu | ((u64)gExt[base + pos] << 32);
+			lastCur = cu;
+			++kept;
+		}
+		pos = gBack[base + pos];
+	}
+	slot[ub - 2 - kept] = (u64)(u32)r.curBegin | ((u64)(u32)r.extBegin << 32);
+	slot[ub - 1] = (u64)(u32)r.curEnd | ((u64)(u32)r.extEnd << 32);
+	matchCnt[p] = (u32)kept + 2;
 }
 
 template <class T>
@@ -528,7 +570,7 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 // Device part of one chunk of queries [qa, qb): seed collection -> sort -> groups ->
 // chaining -> (edit distance) -> compacted primaries in c->hPrim / offsets in c->hOff.
 // Returns false (nothing done) when the chunk's hits exceed the budget and it can be split.
-struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems; };
+struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems, nMatchSlots; };
 
 static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, const u32* hq,
 						const u64* hQKmerOff, u32 qa, u32 qb, u64 hitBudget, ChunkResult* res)
@@ -608,11 +650,34 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dPrimCnt.p, c->dPrimOff.p, nq); }
 	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
 	c->dPrimOut.reserve((nPrim + 1) * sizeof(PrimRec));
+	const bool keepAln = p->keep_alignment;
+	if (keepAln) { c->dPrimNode.reserve(nPrim + 1); c->dPrimBase.reserve(nPrim + 1); c->dMatchSize.reserve(nPrim + 1);
+				   c->dMatchOff.reserve(nPrim + 2); c->dMatchCnt.reserve(nPrim + 1); }
 	{ ScopedK t(c->timer, "k_prim_gather");
 	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dGroupStart.p, c->dHitKey.p,
 						 c->dCur.p, c->dExt.p, c->dCand.p, c->dLen.p, c->firstId, k, c->dFiltOff.p, c->dFiltPos.p,
-						 c->dPrimOff.p, (PrimRec*)c->dPrimOut.p); }
+						 c->dPrimOff.p, (PrimRec*)c->dPrimOut.p, keepAln ? c->dPrimNode.p : (u64*)nullptr,
+						 keepAln ? c->dPrimBase.p : (u64*)nullptr, keepAln ? c->dMatchSize.p : (u64*)nullptr); }
 	if (p->nucl_alignment) fgEditDistances(c, (PrimRec*)c->dPrimOut.p, nPrim, p->use_hpc);
+	res->nMatchSlots = 0;
+	if (keepAln && nPrim)
+	{
+		if (nPrim >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "too many overlaps in one chunk"};
+		{ ScopedK t(c->timer, "k_exscan");
+		  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dMatchSize.p, c->dMatchOff.p, (u32)nPrim); }
+		const u64 slots = fetchScalar(c, c->dMatchOff.p + nPrim);
+		res->nMatchSlots = slots;
+		c->dMatches.reserve(slots + 1);
+		{ ScopedK t(c->timer, "k_chain_matches");
+		  hipLaunchKernelGGL(k_chain_matches, (unsigned)((nPrim + WG - 1) / WG), WG, 0, s, (const PrimRec*)c->dPrimOut.p, nPrim,
+							 c->dPrimNode.p, c->dPrimBase.p, c->dMatchOff.p, c->dCur.p, c->dExt.p, c->dBack.p, k,
+							 c->dMatches.p, c->dMatchCnt.p); }
+		c->hMatches.reserve(slots + 1); c->hMatchOff.reserve(nPrim + 1); c->hMatchCnt.reserve(nPrim + 1);
+		ScopedK t(c->timer, "copy_results_d2h");
+		HIP_CHECK(hipMemcpyAsync(c->hMatches.p, c->dMatches.p, slots * 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(c->hMatchOff.p, c->dMatchOff.p, (nPrim + 1) * 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(c->hMatchCnt.p, c->dMatchCnt.p, nPrim * 4, hipMemcpyDeviceToHost, s));
+	}
 	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
 	c->hOff.reserve(3 * (size_t)(nq + 1));
 	{ ScopedK t(c->timer, "copy_results_d2h");
@@ -660,6 +725,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	if (nq == 0)
 	{
 		out->query_off = own->queryOff.data(); out->div_stats_off = own->statOff.data();
+		if (p->keep_alignment) { own->matchOff.assign(1, 0); out->match_off = own->matchOff.data(); }
 		HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 		return;
 	}
@@ -687,6 +753,8 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		}
 		for (size_t i = chunks.size(); i-- > 0;) todo.push_back(chunks[i]);
 	}
+	const bool keepAln = p->keep_alignment;
+	std::vector<u64> mData, mOff(1, 0);	// keep_alignment: compacted kmerMatches per primary
 	std::vector<PrimRec> primStore;		// only used when there is more than one chunk
 	std::vector<u64> primOffAll(nq + 1, 0);
 	const bool single = todo.size() == 1;
@@ -714,6 +782,17 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			const PrimRec* src = (const PrimRec*)c->hPrim.p;
 			primStore.insert(primStore.end(), src, src + cr.nPrim);
 		}
+		if (keepAln)
+		{
+			mData.reserve(mData.size() + cr.nMatchSlots);
+			for (u64 j = 0; j < cr.nPrim; ++j)
+			{
+				const u64 slotEnd = c->hMatchOff.p[j + 1];
+				const u32 cnt = c->hMatchCnt.p[j];
+				mData.insert(mData.end(), c->hMatches.p + slotEnd - cnt, c->hMatches.p + slotEnd);
+				mOff.push_back(mData.size());
+			}
+		}
 		nPrim += cr.nPrim;
 	}
 	HIP_CHECK(hipEventRecord(evB, s));
@@ -732,6 +811,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	std::vector<float> div(nPrim);
 	std::vector<uint8_t> keep(nPrim, 0);
 	std::vector<u32> nStat(nq, 0);
+	std::vector<u64> nMatch(keepAln ? nq : 0, 0);
 	std::vector<std::vector<float>> statVals;
 	unsigned nThreads = std::thread::hardware_concurrency();
 	nThreads = std::max(1u, std::min(nThreads, 32u));
@@ -768,7 +848,11 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				if (nucl)	// alignment.cpp:244-245
 					d = (float)r.editDistance / std::max((size_t)r.hpcLenExt, (size_t)r.hpcLenCur);
 				div[j] = d;
-				if (d < maxDiv) { keep[j] = 1; ++detected; }
+				if (d < maxDiv)
+				{
+					keep[j] = 1; ++detected;
+					if (keepAln) nMatch[qi] += mOff[j + 1] - mOff[j];
+				}
 				const size_t w = r.curBegin / STAT_WND;
 				if (r.curEnd - r.curBegin > wnd[w].range) { wnd[w].range = r.curEnd - r.curBegin; wnd[w].div = d; }
 			}
@@ -794,6 +878,15 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	own->reserveRecs(own->queryOff[nq]);
 	own->nRecs = own->queryOff[nq];
+	std::vector<u64> qMatchOff;		// first pair of each query's records
+	if (keepAln)
+	{
+		qMatchOff.assign(nq + 1, 0);
+		for (u32 qi = 0; qi < nq; ++qi) qMatchOff[qi + 1] = qMatchOff[qi] + nMatch[qi];
+		own->reserveMatches(qMatchOff[nq]);
+		own->matchOff.assign(own->nRecs + 1, 0);
+		own->matchOff[own->nRecs] = qMatchOff[nq];
+	}
 	own->stats.clear();
 	own->stats.reserve(own->statOff[nq]);
 	for (unsigned t = 0; t < nThreads; ++t) own->stats.insert(own->stats.end(), statVals[t].begin(), statVals[t].end());
@@ -804,10 +897,18 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		{
 			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
 			fg_overlap_rec* dst = own->recs + own->queryOff[qi];
+			u64 mo = keepAln ? qMatchOff[qi] : 0;
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
 				if (!keep[j]) continue;
 				const PrimRec& r = hPrim[j];
+				if (keepAln)
+				{
+					const u64 cnt = mOff[j + 1] - mOff[j];
+					own->matchOff[dst - own->recs] = mo;
+					memcpy(own->matches + 2 * mo, mData.data() + mOff[j], cnt * 8);	// (cur, ext) int32 pairs
+					mo += cnt;
+				}
 				fg_overlap_rec o;
 				o.cur_id = queryIds[qi]; o.ext_id = r.extId;
 				o.cur_begin = r.curBegin; o.cur_end = r.curEnd; o.cur_len = curLen;
@@ -826,6 +927,12 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	out->n_div_stats = own->stats.size();
 	out->div_stats_off = own->statOff.data();
 	out->div_stats = own->stats.data();
+	if (keepAln)
+	{
+		out->n_matches = own->matchOff[own->nRecs];
+		out->match_off = own->matchOff.data();
+		out->matches = own->matches;
+	}
 	float ms = 0;
 	HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
 	out->device_seconds = ms * 1e-3;

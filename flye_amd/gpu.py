@@ -66,7 +66,8 @@ class DetectorParams(C.Structure):
 class OverlapBatch(C.Structure):
     _fields_ = [("n_queries", C.c_uint32), ("n_recs", C.c_uint64), ("query_off", C.c_void_p),
                 ("recs", C.c_void_p), ("n_div_stats", C.c_uint64), ("div_stats_off", C.c_void_p),
-                ("div_stats", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
+                ("div_stats", C.c_void_p), ("n_matches", C.c_uint64), ("match_off", C.c_void_p),
+                ("matches", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
                 ("seed_hits", C.c_uint64), ("dp_groups", C.c_uint64), ("dp_elements", C.c_uint64),
                 ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
 
@@ -148,6 +149,11 @@ class OverlapResult:
         self.stat_off = arena.view(b.div_stats_off, C.c_uint64, nq + 1, np.uint64)
         self.recs = arena.view(b.recs, C.c_uint8, b.n_recs * REC_DTYPE.itemsize, REC_DTYPE)
         self.stats = arena.view(b.div_stats, C.c_float, b.n_div_stats, np.float32)
+        # keep_alignment: kmerMatches of recs[i] = matches[match_off[i]:match_off[i+1]] ((cur, ext) rows)
+        self.match_off = self.matches = None
+        if b.match_off:
+            self.match_off = arena.view(b.match_off, C.c_uint64, b.n_recs + 1, np.uint64)
+            self.matches = arena.view(b.matches, C.c_int32, 2 * b.n_matches, np.int32).reshape(-1, 2)
         self.query_bp, self.query_kmers = b.query_bp, b.query_kmers
         self.seed_hits, self.dp_groups, self.dp_elements = b.seed_hits, b.dp_groups, b.dp_elements
         self.device_seconds = b.device_seconds
@@ -155,12 +161,31 @@ class OverlapResult:
     def of(self, i):
         return self.recs[int(self.query_off[i]):int(self.query_off[i + 1])]
 
+    def kmerMatches(self, i):
+        """OverlapRange::kmerMatches of record i (keep_alignment detectors only)."""
+        return self.matches[int(self.match_off[i]):int(self.match_off[i + 1])]
+
+    def match_digests(self):
+        """(count, order-sensitive 64-bit digest) per record:
+        sum_j (j+1) * (cur_j * 0x9E3779B97F4A7C15 + ext_j + 1) mod 2^64."""
+        off = self.match_off.astype(np.int64)
+        m = self.matches.astype(np.int64).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            v = m[:, 0] * np.uint64(0x9E3779B97F4A7C15) + m[:, 1] + np.uint64(1)
+            j = np.arange(len(m), dtype=np.int64) - np.repeat(off[:-1], np.diff(off)) + 1
+            cs = np.concatenate([[np.uint64(0)], np.cumsum(v * j.astype(np.uint64), dtype=np.uint64)])
+            return np.diff(off), cs[off[1:]] - cs[off[:-1]]
+
     def lines(self):
         r = self.recs
         bits = r["seq_divergence"].view(np.uint32)
-        return [f"{r['cur_id'][i]} {r['cur_begin'][i]} {r['cur_end'][i]} {r['cur_len'][i]} "
-                f"{r['ext_id'][i]} {r['ext_begin'][i]} {r['ext_end'][i]} {r['ext_len'][i]} "
-                f"{r['score'][i]} {bits[i]:08x}" for i in range(len(r))]
+        out = [f"{r['cur_id'][i]} {r['cur_begin'][i]} {r['cur_end'][i]} {r['cur_len'][i]} "
+               f"{r['ext_id'][i]} {r['ext_begin'][i]} {r['ext_end'][i]} {r['ext_len'][i]} "
+               f"{r['score'][i]} {bits[i]:08x}" for i in range(len(r))]
+        if self.match_off is not None:
+            cnt, dg = self.match_digests()
+            out = [f"{l} {cnt[i]} {int(dg[i]):016x}" for i, l in enumerate(out)]
+        return out
 
 
 class Context:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 1
+#define FG_ABI_VERSION 2
 
 enum {
 	FG_OK = 0,
@@ -121,7 +121,9 @@ struct fg_detector_params {
 	int32_t max_jump;
 	int32_t min_overlap;
 	int32_t max_overhang;          /* 0 => _checkOverhang = false */
-	uint8_t keep_alignment;        /* kmerMatches output: FG_ERR_UNSUPPORTED if set */
+	uint8_t keep_alignment;        /* 1: also return every overlap's kmerMatches (the chain thinned
+	                                  to one match per > k query bases, overlap.cpp:368-377,
+	                                  398-405) in fg_overlap_batch.matches */
 	uint8_t only_max_ext;          /* 1: best overlap per target (assemble); 0: all primaries
 	                                  not contained in a better one (overlap.cpp:441-458) */
 	uint8_t nucl_alignment;        /* base-level divergence (alignment.cpp:218-247) */
@@ -156,6 +158,11 @@ struct fg_overlap_batch {
 	uint64_t n_div_stats;
 	uint64_t* div_stats_off;       /* n_queries + 1 */
 	float*   div_stats;            /* OvlpDivStats::add() values (:488-506) */
+	/* keep_alignment only (else 0 / NULL): OverlapRange::kmerMatches of recs[i] is the
+	 * (cur, ext) int32 pairs matches[2*match_off[i]] .. matches[2*match_off[i+1]-1] */
+	uint64_t n_matches;            /* pairs in total */
+	uint64_t* match_off;           /* n_recs + 1 */
+	int32_t* matches;
 	/* work counters of this call (for the roofline's m and d) */
 	uint64_t query_bp, query_kmers, seed_hits, dp_groups, dp_elements;
 	double   device_seconds;       /* HIP-event time of the whole call */

@@ -71,6 +71,8 @@ struct Ctx {
 	std::vector<u64> outOff, statOff;
 	std::vector<fg_overlap_rec> outRecs;
 	std::vector<float> outStats;
+	std::vector<u64> outMatchOff;		// keep_alignment: per output record, in pairs
+	std::vector<int32_t> outMatches;	// (cur, ext) pairs
 	u64 cntKmers = 0, cntHits = 0, cntGroups = 0, cntDp = 0, cntBp = 0;
 };
 
@@ -551,6 +553,7 @@ int editDistance(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
 struct Cand {
 	int32_t curBegin, curEnd, extBegin, extEnd, score, chainLength, filtered;
 	float div;
+	std::vector<std::pair<int32_t, int32_t>> matches;	// kmerMatches (keep_alignment)
 };
 
 // overlap.cpp:29-69 overlapTest
@@ -590,7 +593,8 @@ struct Scratch {
 
 // overlap.cpp:99-508 getSeqOverlaps for one FastaRecord (recIdx = id - firstId)
 void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool forceLocal, int maxOverlaps,
-				 Scratch& S, std::vector<fg_overlap_rec>& out, std::vector<float>& stats, u64* counters)
+				 Scratch& S, std::vector<fg_overlap_rec>& out, std::vector<float>& stats, u64* counters,
+				 std::vector<std::vector<std::pair<int32_t, int32_t>>>* outMatches = nullptr)
 {
 	const Index& ix = c.idx;
 	const int k = c.k;
@@ -715,10 +719,15 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			if (S.back[start] == -1) continue;
 			int32_t last = start, first = 0, chainLength = 0;
 			int32_t pos = start;
+			std::vector<std::pair<int32_t, int32_t>> kmerMatches;
 			while (pos != -1)
 			{
 				first = pos;
 				++chainLength;
+				// chain thinned to one match per > k query bases (:368-377)
+				if (P.keep_alignment &&
+					(kmerMatches.empty() || kmerMatches.back().first - M[pos].cur > k))
+					kmerMatches.emplace_back(M[pos].cur, M[pos].ext);
 				int32_t np = S.back[pos];
 				S.back[pos] = -1;
 				pos = np;
@@ -729,6 +738,13 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			o.score = S.score[last] - S.score[first] + k - 1;
 			o.chainLength = chainLength;
 			if (!overlapTest(P, curId, extId, curLen, extLen, o, forceLocal)) continue;
+			if (P.keep_alignment)	// :398-405
+			{
+				kmerMatches.emplace_back(o.curBegin, o.extBegin);
+				std::reverse(kmerMatches.begin(), kmerMatches.end());
+				kmerMatches.emplace_back(o.curEnd, o.extEnd);
+				o.matches.swap(kmerMatches);
+			}
 			int32_t fpos = 0;
 			for (int32_t p : S.filtered)
 			{
@@ -782,7 +798,11 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 				div = (float)d / std::max(S.sb.size(), S.sa.size());
 			}
 			r.seq_divergence = div;
-			if (div < P.max_divergence) { out.push_back(r); ++detected; }
+			if (div < P.max_divergence)
+			{
+				out.push_back(r); ++detected;
+				if (outMatches) outMatches->push_back(o.matches);
+			}
 			size_t w = o.curBegin / STAT_WND;
 			if (o.curEnd - o.curBegin > wnd[w].range) { wnd[w].range = o.curEnd - o.curBegin; wnd[w].div = div; }
 		}
@@ -799,8 +819,9 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 {
 	Ctx& c = h->c;
 	if (!c.idx.built) return FG_ERR_STATE;
-	if (P->keep_alignment || P->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	if (P->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
 	std::vector<std::vector<fg_overlap_rec>> res(nq);
+	std::vector<std::vector<std::vector<std::pair<int32_t, int32_t>>>> mt(nq);
 	std::vector<std::vector<float>> st(nq);
 	int T = std::max(1, threads);
 	std::vector<Scratch> scratch(T);
@@ -811,8 +832,17 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 		if (queryIds[i] < qBase || queryIds[i] - qBase >= 2 * qCount) return FG_ERR_ARG;
 	parallelFor(nq, T, [&](u32 i, int t)
 	{
-		seqOverlaps(c, *P, queryIds[i] - qBase, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data());
+		seqOverlaps(c, *P, queryIds[i] - qBase, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data(),
+					P->keep_alignment ? &mt[i] : nullptr);
 	});
+	c.outMatchOff.assign(1, 0); c.outMatches.clear();
+	if (P->keep_alignment)
+		for (u32 i = 0; i < nq; ++i)
+			for (auto& v : mt[i])
+			{
+				for (auto& pr : v) { c.outMatches.push_back(pr.first); c.outMatches.push_back(pr.second); }
+				c.outMatchOff.push_back(c.outMatches.size() / 2);
+			}
 	c.outOff.assign(nq + 1, 0); c.statOff.assign(nq + 1, 0);
 	c.outRecs.clear(); c.outStats.clear();
 	c.cntBp = 0;
@@ -850,6 +880,16 @@ int fo_fetch(fo_ctx* h, u64* queryOff, fg_overlap_rec* recs, u64* statOff, float
 		counters[3] = c.cntGroups; counters[4] = c.cntDp;
 	}
 	return 0;
+}
+
+// kmerMatches of the records of the last fo_overlaps call (keep_alignment): matchOff has
+// nRecs + 1 entries (in pairs), matches 2 ints (cur, ext) per pair
+u64 fo_fetch_matches(fo_ctx* h, u64* matchOff, int32_t* matches)
+{
+	Ctx& c = h->c;
+	if (matchOff) memcpy(matchOff, c.outMatchOff.data(), c.outMatchOff.size() * 8);
+	if (matches) memcpy(matches, c.outMatches.data(), c.outMatches.size() * 4);
+	return c.outMatches.size() / 2;
 }
 
 // exact NW edit distance of two 0..3 strings (kernel-level parity tests)

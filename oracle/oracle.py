@@ -43,12 +43,12 @@ class DetectorParams(C.Structure):
 
 
 def detector_params(cfg: dict, min_overlap=1000, max_divergence=1.0, only_max_ext=True, max_overhang=None,
-                    nucl_alignment=None):
+                    nucl_alignment=None, keep_alignment=False):
     """OverlapDetector ctor arguments as main_assemble.cpp:229-238 passes them (or, with the
     overrides, as read_aligner.cpp:186-192 does)."""
     return DetectorParams(max_jump=int(cfg["maximum_jump"]), min_overlap=int(min_overlap),
                           max_overhang=int(cfg["maximum_overhang"] if max_overhang is None else max_overhang),
-                          keep_alignment=0, only_max_ext=int(only_max_ext),
+                          keep_alignment=int(keep_alignment), only_max_ext=int(only_max_ext),
                           nucl_alignment=int(bool(cfg["reads_base_alignment"]) if nucl_alignment is None
                                              else bool(nucl_alignment)),
                           partition_bad_mappings=0, use_hpc=int(bool(cfg["hpc_scoring_on"])),
@@ -83,6 +83,8 @@ def lib():
                                   C.c_int32, C.c_uint8, C.c_int, C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint64)]
         L.fo_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.fo_fetch_matches.restype = C.c_uint64
+        L.fo_fetch_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_edit_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.fo_introsort_mismatches.restype = C.c_int64
         L.fo_introsort_mismatches.argtypes = [C.c_void_p, C.c_int64]
@@ -136,9 +138,14 @@ class OverlapResult:
         """Canonical text form shared with ref_dumper's --ovlp-out."""
         r = self.recs
         bits = r["seq_divergence"].view(np.uint32)
-        return [f"{r['cur_id'][i]} {r['cur_begin'][i]} {r['cur_end'][i]} {r['cur_len'][i]} "
-                f"{r['ext_id'][i]} {r['ext_begin'][i]} {r['ext_end'][i]} {r['ext_len'][i]} "
-                f"{r['score'][i]} {bits[i]:08x}" for i in range(len(r))]
+        out = [f"{r['cur_id'][i]} {r['cur_begin'][i]} {r['cur_end'][i]} {r['cur_len'][i]} "
+               f"{r['ext_id'][i]} {r['ext_begin'][i]} {r['ext_end'][i]} {r['ext_len'][i]} "
+               f"{r['score'][i]} {bits[i]:08x}" for i in range(len(r))]
+        if getattr(self, "match_off", None) is not None:   # keep_alignment: + count and digest of kmerMatches
+            h = match_hashes(self.match_off, self.matches)
+            cnt = np.diff(self.match_off.astype(np.int64))
+            out = [f"{l} {cnt[i]} {int(h[i]):016x}" for i, l in enumerate(out)]
+        return out
 
 
 class Oracle:
@@ -227,7 +234,28 @@ class Oracle:
         cnt = np.zeros(5, np.uint64)
         self.L.fo_fetch(self.h, qo.ctypes.data, recs.ctypes.data, so.ctypes.data, stats.ctypes.data,
                         cnt.ctypes.data)
-        return OverlapResult(qo, recs, so, stats, cnt)
+        res = OverlapResult(qo, recs, so, stats, cnt)
+        if params.keep_alignment:
+            nm = self.L.fo_fetch_matches(self.h, None, None)
+            res.match_off = np.empty(nr.value + 1, np.uint64)
+            res.matches = np.empty((nm, 2), np.int32)
+            self.L.fo_fetch_matches(self.h, res.match_off.ctypes.data, res.matches.ctypes.data)
+        return res
+
+
+def match_hashes(match_off: np.ndarray, matches: np.ndarray) -> np.ndarray:
+    """Order-sensitive 64-bit digest of each record's kmerMatches list:
+    sum_i (i+1) * (cur_i * 0x9E3779B97F4A7C15 + ext_i + 1) mod 2^64.  The golden files
+    store (count, digest) per overlap instead of the lists themselves."""
+    off = match_off.astype(np.int64)
+    n = len(off) - 1
+    m = matches.astype(np.int64).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        v = m[:, 0] * np.uint64(0x9E3779B97F4A7C15) + m[:, 1] + np.uint64(1)
+        idx = np.arange(len(m), dtype=np.int64) - np.repeat(off[:-1], np.diff(off)) + 1
+        v = v * idx.astype(np.uint64)
+        cs = np.concatenate([[np.uint64(0)], np.cumsum(v, dtype=np.uint64)])
+        return (cs[off[1:]] - cs[off[:-1]]) if n else np.zeros(0, np.uint64)
 
 
 def edit_distance(a: np.ndarray, b: np.ndarray) -> int:
@@ -256,7 +284,7 @@ def have_ref() -> bool:
 def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, max_overlaps=0,
             force_local=False, min_overlap=1000, div_mode="none", index_out=None, ovlp_out=None,
             query_limit=None, rc_queries=False, queries_fasta=None, only_max=None, max_overhang=None,
-            nucl_aln=None):
+            nucl_aln=None, keep_aln=False):
     cmd = [REF_DUMPER, "--reads", fasta, "--threads", str(threads), "--min-read-len", str(min_read_len),
            "--max-overlaps", str(max_overlaps), "--force-local", str(int(force_local)),
            "--min-overlap", str(min_overlap), "--div-mode", div_mode]
@@ -280,6 +308,8 @@ def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, m
         cmd += ["--max-overhang", str(int(max_overhang))]
     if nucl_aln is not None:
         cmd += ["--nucl-aln", str(int(nucl_aln))]
+    if keep_aln:
+        cmd += ["--keep-aln", "1"]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True)
     return json.loads(out.stdout.strip().splitlines()[-1])
 

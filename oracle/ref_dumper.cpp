@@ -52,7 +52,7 @@ static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 int main(int argc, char** argv)
 {
 	std::string reads, queriesFile, params, config, indexOut, ovlpOut, divMode = "none";
-	int onlyMax = 1, maxOverhang = -1, nuclAln = -1;
+	int onlyMax = 1, maxOverhang = -1, nuclAln = -1, keepAln = 0;
 	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
 	int minOverlap = 1000;	// main_assemble.cpp:174
 	long queryLimit = -1;
@@ -78,6 +78,7 @@ int main(int argc, char** argv)
 		else if (a == "--only-max") onlyMax = atoi(next().c_str());
 		else if (a == "--max-overhang") maxOverhang = atoi(next().c_str());
 		else if (a == "--nucl-aln") nuclAln = atoi(next().c_str());
+		else if (a == "--keep-aln") keepAln = atoi(next().c_str());
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	if (!config.empty()) Config::load(config);
@@ -158,7 +159,7 @@ int main(int argc, char** argv)
 						 (int)Config::get("maximum_jump"),
 						 Parameters::get().minimumOverlap,
 						 maxOverhang >= 0 ? maxOverhang : (int)Config::get("maximum_overhang"),
-						 /*store alignment*/ false, /*only max*/ (bool)onlyMax,
+						 /*store alignment*/ (bool)keepAln, /*only max*/ (bool)onlyMax,
 						 /*no div threshold*/ 1.0f,
 						 nuclAln >= 0 ? (bool)nuclAln : (bool)Config::get("reads_base_alignment"),
 						 /*partition bad*/ false,
@@ -203,9 +204,21 @@ int main(int argc, char** argv)
 		for (auto& vec : results)
 			for (auto& o : vec)
 			{
-				fprintf(f, "%u %d %d %d %u %d %d %d %d %08x\n", o.curId._id, o.curBegin,
+				fprintf(f, "%u %d %d %d %u %d %d %d %d %08x", o.curId._id, o.curBegin,
 						o.curEnd, o.curLen, o.extId._id, o.extBegin, o.extEnd, o.extLen,
 						o.score, fbits(o.seqDivergence));
+				if (keepAln)
+				{
+					// (count, order-sensitive digest) of kmerMatches, see oracle.py match_hashes
+					unsigned long long h = 0, i = 0;
+					size_t cnt = o.kmerMatches ? o.kmerMatches->size() : 0;
+					if (o.kmerMatches)
+						for (auto& m : *o.kmerMatches)
+							h += (++i) * ((unsigned long long)(long long)m.first * 0x9E3779B97F4A7C15ULL +
+										  (unsigned long long)(long long)m.second + 1ULL);
+					fprintf(f, " %zu %016llx", cnt, h);
+				}
+				fprintf(f, "\n");
 				++total;
 			}
 		fclose(f);

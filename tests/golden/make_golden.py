@@ -64,6 +64,24 @@ CASES = [
                   max_len=30000, read_seed=7, n_repeat_families=8),
          queries_sim=dict(seed=109, genome_len=60_000, coverage=10, kind="hifi", read_seed=9, n_repeat_families=8),
          min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True),
+    # keepAlignment = true (kmerMatches of every overlap; the files hold count + digest per
+    # overlap, oracle.py match_hashes): the ReadAligner flag set in full (read_aligner.cpp:186-192)
+    # and an assemble-style run with the chains kept
+    dict(name="edges_raw_aln", preset="raw",
+         sim=dict(seed=111, genome_len=60_000, coverage=3, kind="hifi03", median_len=20000, min_len=8000,
+                  max_len=30000, read_seed=7, n_repeat_families=6),
+         queries_sim=dict(seed=111, genome_len=60_000, coverage=10, kind="ont_raw", read_seed=9, n_repeat_families=6),
+         min_read_len=0, min_overlap=100, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True,
+         keep_aln=True),
+    dict(name="edges_hifi_aln", preset="hifi",
+         sim=dict(seed=112, genome_len=50_000, coverage=3, kind="hifi03", median_len=20000, min_len=8000,
+                  max_len=30000, read_seed=7, n_repeat_families=8, n_tandems=30),
+         queries_sim=dict(seed=112, genome_len=50_000, coverage=8, kind="hifi", read_seed=9, n_repeat_families=8,
+                          n_tandems=30),
+         min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=False, minimizer_index=True,
+         keep_aln=True),
+    dict(name="raw_pb_aln", preset="raw", sim=dict(seed=113, genome_len=40_000, coverage=25, kind="pb_raw"),
+         min_read_len=1000, keep_aln=True),
 ]
 
 
@@ -101,7 +119,8 @@ def main():
                              force_local=case.get("force_local", False),
                              div_mode=case.get("div_mode", "none"),
                              index_out=os.path.join(tmp, "index.txt"), ovlp_out=os.path.join(tmp, "ovlp.txt"),
-                             rc_queries=case.get("rc_queries", False), **extra)
+                             rc_queries=case.get("rc_queries", False), keep_aln=case.get("keep_aln", False),
+                             **extra)
             hdr, ix = O.parse_ref_index(os.path.join(tmp, "index.txt"), rs)
             lines = open(os.path.join(tmp, "ovlp.txt")).read()
             first = lines.split("\n", 1)[0].split()

@@ -53,4 +53,5 @@ def edges_setup(case, cfg):
     """(window, detector kwargs) of a ReadAligner-style golden case."""
     wnd = int(cfg["minimizer_window"]) if cfg["use_minimizers"] else 1
     return wnd, dict(min_overlap=case["min_overlap"], only_max_ext=bool(case["only_max"]),
-                     max_overhang=case["max_overhang"], nucl_alignment=case["nucl_aln"])
+                     max_overhang=case["max_overhang"], nucl_alignment=case["nucl_aln"],
+                     **({"keep_alignment": True} if case.get("keep_aln") else {}))

@@ -21,7 +21,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/flye_gpu.h but not exported"
     assert set(gpu.ABI_SYMBOLS) <= set(names)
-    assert lib.fg_abi_version() == 1
+    assert lib.fg_abi_version() == 2
 
 
 def test_error_strings_and_argument_checks(built):

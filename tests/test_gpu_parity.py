@@ -11,7 +11,7 @@ from helpers import (bits_to_float, case_queries, check_index_stats, golden_line
 
 pytestmark = pytest.mark.gpu
 
-GOLDEN_CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max"]
+GOLDEN_CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max", "raw_pb_aln"]
 
 
 def _gpu_setup(rs, cfg):
@@ -47,6 +47,7 @@ def test_golden_reference_vectors(built, golden_cases, name):
     check_index_stats(st, case["index"])
     assert index_digest(vi.export()) == case["index"]["sha256"]
     det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    det.p.keep_alignment = int(case.get("keep_aln", False))
     res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
                                   maxOverlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
@@ -63,6 +64,10 @@ def test_golden_reference_vectors(built, golden_cases, name):
     (7, "pb_raw", dict(preset="hifi", cov=20)),     # divergent pairs through the edit-distance kernel
     (8, "pb_raw", dict(all_primaries=True, max_overlaps=5, mixed=True)),   # limit is tested per target group
     (9, "hifi", dict(preset="corrected", all_primaries=True, max_overlaps=3, cov=15, rep=10)),
+    # keepAlignment: the kmerMatches lists themselves, element by element
+    (10, "pb_raw", dict(keep_aln=True, mixed=True, tr=40)),
+    (11, "hifi", dict(preset="hifi", keep_aln=True, all_primaries=True, max_overlaps=6, cov=15, rep=10, tr=40)),
+    (12, "ont_raw", dict(keep_aln=True, all_primaries=True, max_div=0.25, hp=40)),
 ])
 def test_against_oracle_variants(built, seed, kind, opts):
     from flye_amd import config, gpu, synth
@@ -79,6 +84,7 @@ def test_against_oracle_variants(built, seed, kind, opts):
     det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
     det.p.max_divergence = opts.get("max_div", 1.0)
     det.p.only_max_ext = 0 if opts.get("all_primaries") else 1
+    det.p.keep_alignment = int(opts.get("keep_aln", False))
     o = O.Oracle(17)
     o.set_reads(rs, first)
     ost = o.build_index(cfg)
@@ -90,9 +96,19 @@ def test_against_oracle_variants(built, seed, kind, opts):
     gres = det.getSeqOverlapsBatch(q, forceLocal=opts.get("force_local", False),
                                    maxOverlaps=opts.get("max_overlaps", 0))
     ores = o.overlaps(O.detector_params(cfg, max_divergence=opts.get("max_div", 1.0),
-                                        only_max_ext=not opts.get("all_primaries")), q,
+                                        only_max_ext=not opts.get("all_primaries"),
+                                        keep_alignment=opts.get("keep_aln", False)), q,
                       max_overlaps=opts.get("max_overlaps", 0), force_local=opts.get("force_local", False))
     assert gres.lines() == ores.lines()
+    if opts.get("keep_aln"):
+        assert np.array_equal(gres.match_off, ores.match_off)
+        assert np.array_equal(gres.matches, ores.matches)
+        assert len(gres.matches) > 2 * len(gres.recs) > 0
+        r0 = gres.recs[0]
+        m0 = gres.kmerMatches(0)
+        assert tuple(m0[0]) == (r0["cur_begin"], r0["ext_begin"]) and tuple(m0[-1]) == (r0["cur_end"], r0["ext_end"])
+    else:
+        assert gres.match_off is None
     assert np.array_equal(gres.query_off, ores.query_off)
     assert np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32))
     for f in ("chain_length", "filtered_positions", "edit_distance", "hpc_len_cur", "hpc_len_ext"):
@@ -108,9 +124,13 @@ def test_against_oracle_variants(built, seed, kind, opts):
     for j, rid in enumerate(sub):
         a, b = part.of(j), gres.of(pos[int(rid)])
         assert a.tobytes() == b.tobytes()
+        if opts.get("keep_aln"):
+            ia, ib = int(part.query_off[j]), int(gres.query_off[pos[int(rid)]])
+            for t in range(len(a)):
+                assert np.array_equal(part.kmerMatches(ia + t), gres.kmerMatches(ib + t))
 
 
-@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max"])
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max", "edges_raw_aln", "edges_hifi_aln"])
 def test_read_aligner_style_golden(built, golden_cases, name):
     """fg_set_queries + only_max_ext = 0: reads from a second container against an index of
     "edge" sequences, every primary overlap (ReadAligner::alignReads flags,
@@ -130,8 +150,8 @@ def test_read_aligner_style_golden(built, golden_cases, name):
     check_index_stats(st, case["index"])
     assert index_digest(vi.export()) == case["index"]["sha256"]
     ctx.set_queries(reads, 2 * edges.n)
-    det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], False,
-                              dk["only_max_ext"], 1.0, dk["nucl_alignment"], False, bool(cfg["hpc_scoring_on"]))
+    det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"],
+                              dk.get("keep_alignment", False), dk["only_max_ext"], 1.0, dk["nucl_alignment"], False, bool(cfg["hpc_scoring_on"]))
     q = (2 * edges.n + np.arange(0, 2 * reads.n)).astype(np.uint32)      # both strands
     mo = case.get("max_overlaps", 0)
     res = det.getSeqOverlapsBatch(q, maxOverlaps=mo)
@@ -230,16 +250,17 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
     rs = synth.simulate(seed=21, genome_len=60_000, coverage=25, kind="pb_raw").filter_min_len(1000)
     cfg = config.preset("raw")
     ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.keep_alignment = 1
     q = np.arange(0, 2 * rs.n, dtype=np.uint32)
     whole = det.getSeqOverlapsBatch(q, maxOverlaps=11)
     base = (whole.recs.tobytes(), whole.query_off.tobytes(), whole.stats.tobytes(), whole.seed_hits,
-            whole.dp_groups, whole.dp_elements)
+            whole.dp_groups, whole.dp_elements, whole.match_off.tobytes(), whole.matches.tobytes())
     for kb, hb in ((200_000, 1 << 40), (1 << 40, 50_000), (90_000, 30_000)):
         monkeypatch.setenv("FG_KMER_BUDGET", str(kb))
         monkeypatch.setenv("FG_HIT_BUDGET", str(hb))
         part = det.getSeqOverlapsBatch(q, maxOverlaps=11)
         got = (part.recs.tobytes(), part.query_off.tobytes(), part.stats.tobytes(), part.seed_hits,
-               part.dp_groups, part.dp_elements)
+               part.dp_groups, part.dp_elements, part.match_off.tobytes(), part.matches.tobytes())
         assert got == base, (kb, hb)
     monkeypatch.delenv("FG_KMER_BUDGET")
     monkeypatch.delenv("FG_HIT_BUDGET")
@@ -277,12 +298,18 @@ def test_edge_cases(built):
     # empty batch
     empty = det.getSeqOverlapsBatch(np.empty(0, np.uint32))
     assert len(empty.recs) == 0 and len(empty.query_off) == 1
-    # unsupported flag combinations fail loudly
     det.p.keep_alignment = 1
+    empty = det.getSeqOverlapsBatch(np.empty(0, np.uint32))
+    assert len(empty.recs) == 0 and len(empty.match_off) == 1 and len(empty.matches) == 0
+    aln = det.getSeqOverlapsBatch(q)
+    assert aln.recs.tobytes() == gres.recs.tobytes()
+    det.p.keep_alignment = 0
+    # unsupported flag combinations fail loudly
+    det.p.partition_bad_mappings = 1
     with pytest.raises(gpu.FlyeGpuError) as e:
         det.getSeqOverlapsBatch(q[:2])
     assert e.value.code == -7
-    det.p.keep_alignment = 0
+    det.p.partition_bad_mappings = 0
     with pytest.raises(gpu.FlyeGpuError):
         det.getSeqOverlapsBatch(np.array([2 * rs2.n + 10], np.uint32))   # id outside the container
     # call order

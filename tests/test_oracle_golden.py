@@ -5,7 +5,7 @@ import pytest
 from helpers import (bits_to_float, case_queries, check_index_stats, golden_lines, golden_reads,
                      index_digest)
 
-CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max"]
+CASES = ["raw_pb", "raw_ont_rc", "raw_div", "raw_local", "hifi", "corrected_local", "hifi_rc_max", "raw_pb_aln"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -20,14 +20,15 @@ def test_oracle_matches_reference_golden(built, golden_cases, name):
     st = o.build_index(cfg)
     check_index_stats(st, case["index"])
     assert index_digest(o.export_index()) == case["index"]["sha256"]
-    p = O.detector_params(cfg, max_divergence=bits_to_float(case["max_div_bits"]))
+    p = O.detector_params(cfg, max_divergence=bits_to_float(case["max_div_bits"]),
+                          keep_alignment=case.get("keep_aln", False))
     res = o.overlaps(p, case_queries(case, rs.n), max_overlaps=case.get("max_overlaps", 0),
                      force_local=case.get("force_local", False))
     assert res.lines() == golden_lines(name)
     assert len(res.recs) == case["n_overlaps"]
 
 
-@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max"])
+@pytest.mark.parametrize("name", ["edges_raw", "edges_hifi", "edges_raw_max", "edges_raw_aln", "edges_hifi_aln"])
 def test_oracle_read_aligner_style_golden(built, golden_cases, name):
     """Queries from a second container against an index of other sequences, all primaries
     (ReadAligner::alignReads flags), vs the reference's output."""
