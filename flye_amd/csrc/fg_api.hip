@@ -234,7 +234,7 @@ int fg_overlaps(fg_ctx* c, const struct fg_detector_params* p, const uint32_t* q
 	if (!c || !p || !out || (n_queries && !query_ids)) return FG_ERR_ARG;
 	memset(out, 0, sizeof(*out));
 	if (!c->indexBuilt) return FG_ERR_STATE;
-	if (p->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	if (p->partition_bad_mappings && max_overlaps != 0) return FG_ERR_UNSUPPORTED;
 	if (p->max_jump <= 0 || p->min_overlap <= 0 || max_overlaps < 0) return FG_ERR_ARG;
 	{
 		const u32 base = c->hasQ ? c->qFirstId : c->firstId;

@@ -277,6 +277,7 @@ struct BatchOwner {
 	fg_overlap_rec* recs = nullptr;
 	size_t recCap = 0, nRecs = 0;
 	std::vector<float> stats;
+	std::vector<uint8_t> needsTrim;	// partition_bad_mappings: nRecs
 	std::vector<u64> matchOff;	// keep_alignment: nRecs + 1, in pairs
 	int32_t* matches = nullptr;	// (cur, ext) pairs
 	size_t matchCap = 0;

@@ -726,6 +726,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	{
 		out->query_off = own->queryOff.data(); out->div_stats_off = own->statOff.data();
 		if (p->keep_alignment) { own->matchOff.assign(1, 0); out->match_off = own->matchOff.data(); }
+		if (p->partition_bad_mappings) { own->needsTrim.assign(1, 0); out->needs_trim = own->needsTrim.data(); }
 		HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 		return;
 	}
@@ -807,6 +808,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	const float sampleRate = c->sampleRate;
 	const float maxDiv = p->max_divergence;
 	const bool nucl = p->nucl_alignment;
+	const bool partition = p->partition_bad_mappings;	// only with maxOverlaps == 0 (fg_api.hip)
 	const int STAT_WND = 10000;
 	std::vector<float> div(nPrim);
 	std::vector<uint8_t> keep(nPrim, 0);
@@ -848,11 +850,9 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				if (nucl)	// alignment.cpp:244-245
 					d = (float)r.editDistance / std::max((size_t)r.hpcLenExt, (size_t)r.hpcLenCur);
 				div[j] = d;
-				if (d < maxDiv)
-				{
-					keep[j] = 1; ++detected;
-					if (keepAln) nMatch[qi] += mOff[j + 1] - mOff[j];
-				}
+				if (d < maxDiv) { keep[j] = 1; ++detected; }
+				else if (partition) { keep[j] = 2; ++detected; }	// handed back for the caller's checkIdyAndTrim
+				if (keep[j] && keepAln) nMatch[qi] += mOff[j + 1] - mOff[j];
 				const size_t w = r.curBegin / STAT_WND;
 				if (r.curEnd - r.curBegin > wnd[w].range) { wnd[w].range = r.curEnd - r.curBegin; wnd[w].div = d; }
 			}
@@ -878,6 +878,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	own->reserveRecs(own->queryOff[nq]);
 	own->nRecs = own->queryOff[nq];
+	if (partition) own->needsTrim.assign(own->nRecs, 0);
 	std::vector<u64> qMatchOff;		// first pair of each query's records
 	if (keepAln)
 	{
@@ -902,6 +903,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			{
 				if (!keep[j]) continue;
 				const PrimRec& r = hPrim[j];
+				if (partition) own->needsTrim[dst - own->recs] = keep[j] == 2;
 				if (keepAln)
 				{
 					const u64 cnt = mOff[j + 1] - mOff[j];
@@ -927,6 +929,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	out->n_div_stats = own->stats.size();
 	out->div_stats_off = own->statOff.data();
 	out->div_stats = own->stats.data();
+	if (partition) out->needs_trim = own->needsTrim.data();
 	if (keepAln)
 	{
 		out->n_matches = own->matchOff[own->nRecs];

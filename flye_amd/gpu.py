@@ -67,7 +67,7 @@ class OverlapBatch(C.Structure):
     _fields_ = [("n_queries", C.c_uint32), ("n_recs", C.c_uint64), ("query_off", C.c_void_p),
                 ("recs", C.c_void_p), ("n_div_stats", C.c_uint64), ("div_stats_off", C.c_void_p),
                 ("div_stats", C.c_void_p), ("n_matches", C.c_uint64), ("match_off", C.c_void_p),
-                ("matches", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
+                ("matches", C.c_void_p), ("needs_trim", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
                 ("seed_hits", C.c_uint64), ("dp_groups", C.c_uint64), ("dp_elements", C.c_uint64),
                 ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
 
@@ -154,6 +154,8 @@ class OverlapResult:
         if b.match_off:
             self.match_off = arena.view(b.match_off, C.c_uint64, b.n_recs + 1, np.uint64)
             self.matches = arena.view(b.matches, C.c_int32, 2 * b.n_matches, np.int32).reshape(-1, 2)
+        # partition_bad_mappings: 1 = failed the divergence gate, there for the caller's checkIdyAndTrim
+        self.needs_trim = arena.view(b.needs_trim, C.c_uint8, b.n_recs, np.uint8) if b.needs_trim else None
         self.query_bp, self.query_kmers = b.query_bp, b.query_kmers
         self.seed_hits, self.dp_groups, self.dp_elements = b.seed_hits, b.dp_groups, b.dp_elements
         self.device_seconds = b.device_seconds

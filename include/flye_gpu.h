@@ -127,7 +127,13 @@ struct fg_detector_params {
 	uint8_t only_max_ext;          /* 1: best overlap per target (assemble); 0: all primaries
 	                                  not contained in a better one (overlap.cpp:441-458) */
 	uint8_t nucl_alignment;        /* base-level divergence (alignment.cpp:218-247) */
-	uint8_t partition_bad_mappings;/* FG_ERR_UNSUPPORTED if set */
+	uint8_t partition_bad_mappings;/* 1: primaries that FAIL the divergence gate are returned too,
+	                                  marked in fg_overlap_batch.needs_trim, in the position
+	                                  where the caller splices in the result of its own
+	                                  checkIdyAndTrim (overlap.cpp:474-485; the ksw2 alignment
+	                                  stays on the host).  Only with max_overlaps = 0, as every
+	                                  caller in the reference uses it (overlap.h:323);
+	                                  FG_ERR_UNSUPPORTED otherwise */
 	uint8_t use_hpc;
 	uint8_t pad_[3];
 	float   max_divergence;        /* OverlapDetector::_maxDivergence (mutable,
@@ -163,6 +169,9 @@ struct fg_overlap_batch {
 	uint64_t n_matches;            /* pairs in total */
 	uint64_t* match_off;           /* n_recs + 1 */
 	int32_t* matches;
+	/* partition_bad_mappings only (else NULL): needs_trim[i] = 1 when recs[i] did not pass
+	 * seq_divergence < max_divergence and is there for the caller's checkIdyAndTrim */
+	uint8_t* needs_trim;           /* n_recs */
 	/* work counters of this call (for the roofline's m and d) */
 	uint64_t query_bp, query_kmers, seed_hits, dp_groups, dp_elements;
 	double   device_seconds;       /* HIP-event time of the whole call */

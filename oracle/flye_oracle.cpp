@@ -71,6 +71,7 @@ struct Ctx {
 	std::vector<u64> outOff, statOff;
 	std::vector<fg_overlap_rec> outRecs;
 	std::vector<float> outStats;
+	std::vector<uint8_t> outTrim;		// partition_bad_mappings: per output record
 	std::vector<u64> outMatchOff;		// keep_alignment: per output record, in pairs
 	std::vector<int32_t> outMatches;	// (cur, ext) pairs
 	u64 cntKmers = 0, cntHits = 0, cntGroups = 0, cntDp = 0, cntBp = 0;
@@ -594,7 +595,8 @@ struct Scratch {
 // overlap.cpp:99-508 getSeqOverlaps for one FastaRecord (recIdx = id - firstId)
 void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool forceLocal, int maxOverlaps,
 				 Scratch& S, std::vector<fg_overlap_rec>& out, std::vector<float>& stats, u64* counters,
-				 std::vector<std::vector<std::pair<int32_t, int32_t>>>* outMatches = nullptr)
+				 std::vector<std::vector<std::pair<int32_t, int32_t>>>* outMatches = nullptr,
+				 std::vector<uint8_t>* outTrim = nullptr)
 {
 	const Index& ix = c.idx;
 	const int k = c.k;
@@ -798,9 +800,14 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 				div = (float)d / std::max(S.sb.size(), S.sa.size());
 			}
 			r.seq_divergence = div;
-			if (div < P.max_divergence)
+			// :470-485; a primary that fails the gate goes to checkIdyAndTrim when
+			// _partitionBadMappings is set: that ksw2 step is not restated here, the record is
+			// emitted in its place and marked (fo_fetch_trim)
+			const bool pass = div < P.max_divergence;
+			if (pass || P.partition_bad_mappings)
 			{
 				out.push_back(r); ++detected;
+				if (outTrim) outTrim->push_back(!pass);
 				if (outMatches) outMatches->push_back(o.matches);
 			}
 			size_t w = o.curBegin / STAT_WND;
@@ -819,8 +826,9 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 {
 	Ctx& c = h->c;
 	if (!c.idx.built) return FG_ERR_STATE;
-	if (P->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	if (P->partition_bad_mappings && maxOverlaps != 0) return FG_ERR_UNSUPPORTED;
 	std::vector<std::vector<fg_overlap_rec>> res(nq);
+	std::vector<std::vector<uint8_t>> trim(nq);
 	std::vector<std::vector<std::vector<std::pair<int32_t, int32_t>>>> mt(nq);
 	std::vector<std::vector<float>> st(nq);
 	int T = std::max(1, threads);
@@ -833,8 +841,11 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 	parallelFor(nq, T, [&](u32 i, int t)
 	{
 		seqOverlaps(c, *P, queryIds[i] - qBase, forceLocal, maxOverlaps, scratch[t], res[i], st[i], cnt[t].data(),
-					P->keep_alignment ? &mt[i] : nullptr);
+					P->keep_alignment ? &mt[i] : nullptr, P->partition_bad_mappings ? &trim[i] : nullptr);
 	});
+	c.outTrim.clear();
+	if (P->partition_bad_mappings)
+		for (u32 i = 0; i < nq; ++i) c.outTrim.insert(c.outTrim.end(), trim[i].begin(), trim[i].end());
 	c.outMatchOff.assign(1, 0); c.outMatches.clear();
 	if (P->keep_alignment)
 		for (u32 i = 0; i < nq; ++i)
@@ -890,6 +901,14 @@ u64 fo_fetch_matches(fo_ctx* h, u64* matchOff, int32_t* matches)
 	if (matchOff) memcpy(matchOff, c.outMatchOff.data(), c.outMatchOff.size() * 8);
 	if (matches) memcpy(matches, c.outMatches.data(), c.outMatches.size() * 4);
 	return c.outMatches.size() / 2;
+}
+
+// needs-trim marks of the records of the last fo_overlaps call (partition_bad_mappings)
+u64 fo_fetch_trim(fo_ctx* h, uint8_t* flags)
+{
+	Ctx& c = h->c;
+	if (flags) memcpy(flags, c.outTrim.data(), c.outTrim.size());
+	return c.outTrim.size();
 }
 
 // exact NW edit distance of two 0..3 strings (kernel-level parity tests)

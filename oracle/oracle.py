@@ -43,7 +43,7 @@ class DetectorParams(C.Structure):
 
 
 def detector_params(cfg: dict, min_overlap=1000, max_divergence=1.0, only_max_ext=True, max_overhang=None,
-                    nucl_alignment=None, keep_alignment=False):
+                    nucl_alignment=None, keep_alignment=False, partition_bad_mappings=False):
     """OverlapDetector ctor arguments as main_assemble.cpp:229-238 passes them (or, with the
     overrides, as read_aligner.cpp:186-192 does)."""
     return DetectorParams(max_jump=int(cfg["maximum_jump"]), min_overlap=int(min_overlap),
@@ -51,7 +51,7 @@ def detector_params(cfg: dict, min_overlap=1000, max_divergence=1.0, only_max_ex
                           keep_alignment=int(keep_alignment), only_max_ext=int(only_max_ext),
                           nucl_alignment=int(bool(cfg["reads_base_alignment"]) if nucl_alignment is None
                                              else bool(nucl_alignment)),
-                          partition_bad_mappings=0, use_hpc=int(bool(cfg["hpc_scoring_on"])),
+                          partition_bad_mappings=int(partition_bad_mappings), use_hpc=int(bool(cfg["hpc_scoring_on"])),
                           max_divergence=float(max_divergence))
 
 
@@ -83,6 +83,8 @@ def lib():
                                   C.c_int32, C.c_uint8, C.c_int, C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint64)]
         L.fo_fetch.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.fo_fetch_trim.restype = C.c_uint64
+        L.fo_fetch_trim.argtypes = [C.c_void_p, C.c_void_p]
         L.fo_fetch_matches.restype = C.c_uint64
         L.fo_fetch_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_edit_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -131,6 +133,7 @@ def _export(fn, handle):
 class OverlapResult:
     def __init__(self, query_off, recs, stat_off, stats, counters):
         self.query_off, self.recs, self.stat_off, self.stats = query_off, recs, stat_off, stats
+        self.needs_trim = self.match_off = self.matches = None
         (self.query_bp, self.query_kmers, self.seed_hits, self.dp_groups,
          self.dp_elements) = [int(x) for x in counters]
 
@@ -235,6 +238,9 @@ class Oracle:
         self.L.fo_fetch(self.h, qo.ctypes.data, recs.ctypes.data, so.ctypes.data, stats.ctypes.data,
                         cnt.ctypes.data)
         res = OverlapResult(qo, recs, so, stats, cnt)
+        if params.partition_bad_mappings:
+            res.needs_trim = np.zeros(nr.value, np.uint8)
+            self.L.fo_fetch_trim(self.h, res.needs_trim.ctypes.data)
         if params.keep_alignment:
             nm = self.L.fo_fetch_matches(self.h, None, None)
             res.match_off = np.empty(nr.value + 1, np.uint64)
@@ -284,7 +290,7 @@ def have_ref() -> bool:
 def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, max_overlaps=0,
             force_local=False, min_overlap=1000, div_mode="none", index_out=None, ovlp_out=None,
             query_limit=None, rc_queries=False, queries_fasta=None, only_max=None, max_overhang=None,
-            nucl_aln=None, keep_aln=False):
+            nucl_aln=None, keep_aln=False, max_div=None):
     cmd = [REF_DUMPER, "--reads", fasta, "--threads", str(threads), "--min-read-len", str(min_read_len),
            "--max-overlaps", str(max_overlaps), "--force-local", str(int(force_local)),
            "--min-overlap", str(min_overlap), "--div-mode", div_mode]
@@ -310,6 +316,8 @@ def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, m
         cmd += ["--nucl-aln", str(int(nucl_aln))]
     if keep_aln:
         cmd += ["--keep-aln", "1"]
+    if max_div is not None:
+        cmd += ["--max-div", repr(float(max_div))]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True)
     return json.loads(out.stdout.strip().splitlines()[-1])
 

@@ -53,6 +53,7 @@ int main(int argc, char** argv)
 {
 	std::string reads, queriesFile, params, config, indexOut, ovlpOut, divMode = "none";
 	int onlyMax = 1, maxOverhang = -1, nuclAln = -1, keepAln = 0;
+	float maxDiv = 1.0f;
 	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
 	int minOverlap = 1000;	// main_assemble.cpp:174
 	long queryLimit = -1;
@@ -79,6 +80,7 @@ int main(int argc, char** argv)
 		else if (a == "--max-overhang") maxOverhang = atoi(next().c_str());
 		else if (a == "--nucl-aln") nuclAln = atoi(next().c_str());
 		else if (a == "--keep-aln") keepAln = atoi(next().c_str());
+		else if (a == "--max-div") maxDiv = strtof(next().c_str(), nullptr);
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	if (!config.empty()) Config::load(config);
@@ -160,7 +162,7 @@ int main(int argc, char** argv)
 						 Parameters::get().minimumOverlap,
 						 maxOverhang >= 0 ? maxOverhang : (int)Config::get("maximum_overhang"),
 						 /*store alignment*/ (bool)keepAln, /*only max*/ (bool)onlyMax,
-						 /*no div threshold*/ 1.0f,
+						 /*div threshold*/ maxDiv,
 						 nuclAln >= 0 ? (bool)nuclAln : (bool)Config::get("reads_base_alignment"),
 						 /*partition bad*/ false,
 						 (bool)Config::get("hpc_scoring_on"));

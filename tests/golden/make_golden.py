@@ -82,6 +82,26 @@ CASES = [
          keep_aln=True),
     dict(name="raw_pb_aln", preset="raw", sim=dict(seed=113, genome_len=40_000, coverage=25, kind="pb_raw"),
          min_read_len=1000, keep_aln=True),
+    # RepeatGraph::build flag set (repeat_graph.cpp:72-97): the assembled sequences against
+    # themselves, all-k-mer / minimizer index with min coverage 1, no overhang check, every primary,
+    # kmerMatches kept, base-level divergence with the gate applied.  (partitionBadMappings is off in
+    # the reference run: its ksw2 step is outside the path; the library returns the gated-out
+    # primaries marked instead, tested against these vectors + a max_div = 1 run.)
+    dict(name="repeat_raw", preset="raw",
+         sim=dict(seed=114, genome_len=60_000, coverage=4, kind="hifi03", median_len=15000, min_len=6000,
+                  max_len=30000, n_repeat_families=8),
+         min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=True, minimizer_index=True,
+         keep_aln=True, max_div=0.006),
+    dict(name="repeat_raw_all", preset="raw",
+         sim=dict(seed=114, genome_len=60_000, coverage=4, kind="hifi03", median_len=15000, min_len=6000,
+                  max_len=30000, n_repeat_families=8),
+         min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=True, minimizer_index=True,
+         keep_aln=True, max_div=1.0),
+    dict(name="repeat_hifi", preset="hifi",
+         sim=dict(seed=115, genome_len=60_000, coverage=4, kind="hifi", median_len=15000, min_len=6000,
+                  max_len=30000, n_repeat_families=8, n_homopolymers=40),
+         min_read_len=0, min_overlap=1000, only_max=False, max_overhang=0, nucl_aln=True, minimizer_index=True,
+         keep_aln=True, max_div=0.015),
 ]
 
 
@@ -106,14 +126,18 @@ def main():
             rs = synth.simulate(fasta_path=fa, **case["sim"]).filter_min_len(case["min_read_len"])
             extra = {}
             params = None
-            if "queries_sim" in case:
-                qfa = os.path.join(tmp, "queries.fasta")
-                synth.simulate(fasta_path=qfa, **case["queries_sim"])
+            if case.get("minimizer_index"):
                 cfgd = config.preset(case["preset"])
                 wnd = int(cfgd["minimizer_window"]) if cfgd["use_minimizers"] else 1
                 params = f"use_minimizers=1,minimizer_window={wnd}"     # read_aligner.cpp:180-182
-                extra = dict(queries_fasta=qfa, only_max=case["only_max"], max_overhang=case["max_overhang"],
+                extra = dict(only_max=case["only_max"], max_overhang=case["max_overhang"],
                              nucl_aln=case["nucl_aln"], min_overlap=case["min_overlap"])
+                if "max_div" in case:
+                    extra["max_div"] = case["max_div"]
+                if "queries_sim" in case:
+                    qfa = os.path.join(tmp, "queries.fasta")
+                    synth.simulate(fasta_path=qfa, **case["queries_sim"])
+                    extra["queries_fasta"] = qfa
             info = O.run_ref(fa, config=CFG_DIR + config.CFG_FILES[case["preset"]], params_string=params, threads=8,
                              min_read_len=case["min_read_len"], max_overlaps=case.get("max_overlaps", 0),
                              force_local=case.get("force_local", False),

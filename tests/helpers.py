@@ -55,3 +55,26 @@ def edges_setup(case, cfg):
     return wnd, dict(min_overlap=case["min_overlap"], only_max_ext=bool(case["only_max"]),
                      max_overhang=case["max_overhang"], nucl_alignment=case["nucl_aln"],
                      **({"keep_alignment": True} if case.get("keep_aln") else {}))
+
+
+def repeat_stage_setup(case, cfg):
+    """(window, detector kwargs) of a RepeatGraph::build-style golden case (repeat_graph.cpp:72-97)
+    with partitionBadMappings on: the primaries that fail the gate come back marked."""
+    wnd, dk = edges_setup(case, cfg)
+    dk.update(max_divergence=float(np.float32(case["max_div"])), partition_bad_mappings=True)
+    return wnd, dk
+
+
+def check_repeat_stage_result(res, case, golden_cases):
+    """`res` (oracle or GPU, partition_bad_mappings = 1, gate = case max_div) against the reference's
+    vectors: the unmarked records are what the reference returns with that gate, marked + unmarked
+    are what it returns with the gate open, and a record is marked iff it fails the gate."""
+    lines = res.lines()
+    trim = res.needs_trim.astype(bool)
+    assert [l for l, t in zip(lines, trim) if not t] == golden_lines(case["name"])
+    all_name = case["name"] + "_all"
+    if all_name in golden_cases:
+        assert lines == golden_lines(all_name)
+    maxd = np.float32(case["max_div"])
+    assert np.array_equal(trim, ~(res.recs["seq_divergence"] < maxd))
+    assert trim.any() and not trim.all()

@@ -179,6 +179,44 @@ def test_read_aligner_style_golden(built, golden_cases, name):
     assert self_res.lines() == o2.overlaps(O.detector_params(cfg, **dk), np.arange(0, 2 * edges.n, 2)).lines()
 
 
+@pytest.mark.parametrize("name", ["repeat_raw", "repeat_hifi"])
+def test_repeat_stage_golden(built, golden_cases, name):
+    """The RepeatGraph::build flag set (repeat_graph.cpp:72-97): keep_alignment, every primary,
+    base-level divergence, partition_bad_mappings (gated-out primaries come back marked for the
+    caller's checkIdyAndTrim) -- vs the reference's vectors and the oracle."""
+    from flye_amd import config, gpu
+    from oracle import oracle as O
+    from helpers import check_repeat_stage_result, repeat_stage_setup
+    case = golden_cases[name]
+    seqs = golden_reads(case)
+    cfg = config.preset(case["preset"])
+    wnd, dk = repeat_stage_setup(case, cfg)
+    ctx = gpu.Context(int(cfg["kmer_size"]), 0)
+    ctx.set_reads(seqs, 0)
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    st = vi.buildIndexMinimizers(1, wnd, cfg["repeat_kmer_rate"])
+    check_index_stats(st, case["index"])
+    det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], True,
+                              dk["only_max_ext"], dk["max_divergence"], dk["nucl_alignment"], True,
+                              bool(cfg["hpc_scoring_on"]))
+    q = np.arange(0, 2 * seqs.n, dtype=np.uint32)      # both strands
+    res = det.getSeqOverlapsBatch(q)
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(seqs, 0)
+    o.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
+    ores = o.overlaps(O.detector_params(cfg, **dk), q)
+    assert res.lines() == ores.lines()
+    assert np.array_equal(res.needs_trim, ores.needs_trim)
+    assert np.array_equal(res.match_off, ores.match_off) and np.array_equal(res.matches, ores.matches)
+    assert np.array_equal(res.stats.view(np.uint32), ores.stats.view(np.uint32))
+    fwd = det.getSeqOverlapsBatch(q[::2])
+    check_repeat_stage_result(fwd, case, golden_cases)
+    # the marks exist only with max_overlaps = 0 (the only way the reference uses the flag)
+    with pytest.raises(gpu.FlyeGpuError) as e:
+        det.getSeqOverlapsBatch(q[:2], maxOverlaps=3)
+    assert e.value.code == -7
+
+
 def _median3_killer(n):
     k = n // 2
     a = np.zeros(n, np.uint64)
@@ -307,7 +345,7 @@ def test_edge_cases(built):
     # unsupported flag combinations fail loudly
     det.p.partition_bad_mappings = 1
     with pytest.raises(gpu.FlyeGpuError) as e:
-        det.getSeqOverlapsBatch(q[:2])
+        det.getSeqOverlapsBatch(q[:2], maxOverlaps=2)
     assert e.value.code == -7
     det.p.partition_bad_mappings = 0
     with pytest.raises(gpu.FlyeGpuError):

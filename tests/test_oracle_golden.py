@@ -51,3 +51,24 @@ def test_oracle_read_aligner_style_golden(built, golden_cases, name):
     res = o.overlaps(O.detector_params(cfg, **dk), q, max_overlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
     assert len(res.recs) == case["n_overlaps"] > 0
+
+
+@pytest.mark.parametrize("name", ["repeat_raw", "repeat_hifi"])
+def test_oracle_repeat_stage_golden(built, golden_cases, name):
+    """RepeatGraph::build flags: sequences against themselves, every primary, kmerMatches kept,
+    base-level divergence; gated-out primaries returned marked (partition_bad_mappings)."""
+    import numpy as np
+    from flye_amd import config
+    from oracle import oracle as O
+    from helpers import check_repeat_stage_result, repeat_stage_setup
+    case = golden_cases[name]
+    seqs = golden_reads(case)
+    cfg = config.preset(case["preset"])
+    wnd, dk = repeat_stage_setup(case, cfg)
+    o = O.Oracle(int(cfg["kmer_size"]))
+    o.set_reads(seqs, 0)
+    st = o.build_index_minimizers(1, wnd, cfg["repeat_kmer_rate"])
+    check_index_stats(st, case["index"])
+    assert index_digest(o.export_index()) == case["index"]["sha256"]
+    res = o.overlaps(O.detector_params(cfg, **dk), np.arange(0, 2 * seqs.n, 2))
+    check_repeat_stage_result(res, case, golden_cases)
