@@ -125,8 +125,12 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	const int lane = threadIdx.x & 63;
 	KT key = lane < n ? K[first + lane] : (KT)0;
 	u32 val = lane < n ? V[first + lane] : 0u;
-	int sp = 0;
+	// pending segments: the smaller part is continued, the larger one waits (only if it is
+	// still > 16), so at most two wait at any time (<= 64 -> <= 32 -> done); a, b, d and the
+	// cut are wave-uniform, the "stack" is two scalar slots
+	int sp = 0, p0a = 0, p0b = 0, p0d = 0, p1a = 0, p1b = 0, p1d = 0;
 	int a = 0, b = n, d = depth;
+	(void)stk;
 	while (true)
 	{
 		while (b - a > 16 && !(g_ablate & 16))
@@ -150,11 +154,18 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 			key = shflk(key, src);
 			val = __shfl(val, src);
 			const int cut = lane_partition(key, val, a + 1, b, pk);
-			if (cut - a < b - cut) { stk[sp++] = cut; stk[sp++] = b; stk[sp++] = d; b = cut; }
-			else { stk[sp++] = a; stk[sp++] = cut; stk[sp++] = d; a = cut; }
+			int oa, ob;
+			if (cut - a < b - cut) { oa = cut; ob = b; b = cut; }
+			else { oa = a; ob = cut; a = cut; }
+			if (ob - oa > 16)
+			{
+				if (sp == 0) { p0a = oa; p0b = ob; p0d = d; } else { p1a = oa; p1b = ob; p1d = d; }
+				++sp;
+			}
 		}
 		if (sp == 0) break;
-		d = stk[--sp]; b = stk[--sp]; a = stk[--sp];
+		--sp;
+		if (sp == 0) { a = p0a; b = p0b; d = p0d; } else { a = p1a; b = p1b; d = p1d; }
 	}
 	// final insertion sort = stable placement.  After the quicksort phase every element
 	// sits inside its own <= 16-element leaf and the leaves are mutually ordered, so the
@@ -165,25 +176,46 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	if (!(g_ablate & 32))
 	{
 		// Each pair of lanes at distance <= 15 is compared once: a copy of every element
-		// travels 15 lanes in one direction; the lane it visits and the visitor both book the
-		// outcome (the visitor in `acc`), and `acc` is brought home by one bpermute.  The
-		// visitor's lane id travels along, so nothing depends on the rotation direction.
-		KT vk = key; int vid = lane; int acc = 0;
-		for (int d = 0; d < 15; ++d)
+		// travels 15 lanes upwards; the lane it visits and the visitor both book the outcome
+		// (the visitor in `acc`, which rotates along and is brought home by one bpermute).
+		// The key copies are SHIFTED (zeros enter at lane 0, and lanes >= n hold the maximum
+		// key), so neither a wrapped-around nor an out-of-range visitor ever counts as greater.
+		const int probe = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_update_dpp(0, lane, 0x13C, 0xf, 0xf, false));
+		if (probe == 63)	// wave_ror:1 / wave_shr:1 hand lane i the value of lane i-1
 		{
-			vk = rot_key<0x13C>(vk);
-			vid = __builtin_amdgcn_update_dpp(0, vid, 0x13C, 0xf, 0xf, false);
-			acc = __builtin_amdgcn_update_dpp(0, acc, 0x13C, 0xf, 0xf, false);
-			const int dist = vid - lane;
-			const bool ok = vid < n && lane < n && dist >= -15 && dist <= 15;
-			const bool fromBelow = dist < 0;
-			// from below: a greater visitor must end up above me; from above: a smaller one below me
-			const int c = (ok && (fromBelow ? (vk > key) : (vk < key))) ? 1 : 0;
-			pos += fromBelow ? -c : c;
-			acc += fromBelow ? c : -c;
+			const KT hk = lane < n ? key : ~(KT)0;	// as a host, a padding lane is never overtaken
+			KT vk = hk; int acc = 0;
+	#pragma unroll
+			for (int d = 0; d < 15; ++d)
+			{
+				vk = rot_key<0x138>(vk);
+				acc = __builtin_amdgcn_update_dpp(0, acc, 0x13C, 0xf, 0xf, false);
+				// a greater visitor from below must end up above me
+				const int c = vk > hk ? 1 : 0;
+				pos -= c;
+				acc += c;
+			}
+			pos += __shfl(acc, (lane + 15) & 63);
 		}
-		const int delta = __builtin_amdgcn_readfirstlane((lane - vid) & 63);
-		pos += __shfl(acc, (lane + delta) & 63);
+		else
+		{
+			// direction-agnostic form: the visitor's lane id travels with the key
+			KT vk = key; int vid = lane; int acc = 0;
+			for (int d = 0; d < 15; ++d)
+			{
+				vk = rot_key<0x13C>(vk);
+				vid = __builtin_amdgcn_update_dpp(0, vid, 0x13C, 0xf, 0xf, false);
+				acc = __builtin_amdgcn_update_dpp(0, acc, 0x13C, 0xf, 0xf, false);
+				const int dist = vid - lane;
+				const bool ok = vid < n && lane < n && dist >= -15 && dist <= 15;
+				const bool fromBelow = dist < 0;
+				const int c = (ok && (fromBelow ? (vk > key) : (vk < key))) ? 1 : 0;
+				pos += fromBelow ? -c : c;
+				acc += fromBelow ? c : -c;
+			}
+			const int delta = __builtin_amdgcn_readfirstlane((lane - vid) & 63);
+			pos += __shfl(acc, (lane + delta) & 63);
+		}
 	}
 	wave_mem_fence();
 	if (lane < n) { K[first + pos] = key; V[first + pos] = val; }
