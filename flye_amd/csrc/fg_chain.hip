@@ -76,7 +76,7 @@ __device__ __forceinline__ void append3(bool a, bool b, bool c, u32 g, u32* list
 	__shared__ u32 wcnt[3][WG / 64];
 	__shared__ u32 base[3];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const u64 mA = __ballot(a), mB = __ballot(b), mC = __ballot(c);
+	const u64 mA = __builtin_amdgcn_ballot_w64(a), mB = __builtin_amdgcn_ballot_w64(b), mC = __builtin_amdgcn_ballot_w64(c);
 	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mA); wcnt[1][wv] = (u32)__popcll(mB); wcnt[2][wv] = (u32)__popcll(mC); }
 	__syncthreads();
 	if (threadIdx.x < 3)
@@ -145,9 +145,9 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	const int lane = threadIdx.x & 63;
 	const u32 li = blockIdx.x * PREP_WAVES + wv;
 	if (li >= nList) return;
-	const u64 g = list[li];
-	const u64 g0 = groupStart[g];
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
 	const u64* K = hitKey + g0;
 	const u32* V = hitVal + g0;
@@ -244,13 +244,13 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	const int lane = threadIdx.x & 63;
 	const u32 li = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
 	if (li >= nList) return;
-	const u64 g = list[li];
-	const u64 g0 = groupStart[g];
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
-	const u32 qrec = query[groupQuery[g]];
-	const u32 extRec = (u32)(hitKey[g0] >> 32) - P.firstId;
-	const bool extSorted = len[extRec >> 1] > qLen[qrec >> 1];
+	const u32 qrec = fg_uni(query[groupQuery[g]]);
+	const u32 extRec = fg_uni((u32)(hitKey[g0] >> 32)) - P.firstId;
+	const bool extSorted = fg_uni(len[extRec >> 1]) > fg_uni(qLen[qrec >> 1]);
 	const u32* cur = gCur + g0;
 	const u32* ext = gExt + g0;
 	i32* score = gScore + g0;
@@ -336,8 +336,8 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 			const bool brkA = inr && jd == 0 && dc < k;
 			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
 			const bool upd = inr && ns > exc;
-			const u64 stopM = __ballot(brkB || (upd && brkA));
-			const u64 updM = __ballot(upd);
+			const u64 stopM = __builtin_amdgcn_ballot_w64(brkB || (upd && brkA));
+			const u64 updM = __builtin_amdgcn_ballot_w64(upd);
 			const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
 			const u64 um = updM & lim;
 			if (um)
@@ -381,9 +381,9 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	const int lane = threadIdx.x & 63;
 	const u32 li = blockIdx.x * FIN_WAVES + wv;
 	if (li >= nList) return;
-	const u64 g = list[li];
-	const u64 g0 = groupStart[g];
-	const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
 	const u32 q = groupQuery[g];
 	const int k = P.k;
@@ -446,7 +446,7 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 		const bool in = oi0 + lane < n;
 		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
 		const i32 bk = in ? back[st] : -1;
-		u64 m = __ballot(bk != -1);
+		u64 m = __builtin_amdgcn_ballot_w64(bk != -1);
 		while (m)
 		{
 			const int l = __ffsll((long long)m) - 1;

@@ -209,6 +209,16 @@ struct fg_ctx {
 // --- device helpers ----------------------------------------------------------
 #if defined(__HIPCC__)
 
+// wave-uniform values loaded through the vector memory path: pinned to SGPRs so that loop
+// control becomes scalar branches and base addresses scalar operands
+__device__ __forceinline__ i32 fg_uni(i32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u32 fg_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 fg_uni(u64 v)
+{
+	return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) |
+		   (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
+
 __device__ __forceinline__ u64 fg_mix(u64 x)
 {
 	x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;

@@ -228,8 +228,12 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 // SORT_CAP elements are queued for k_sort_lds (one wave per piece, entirely in LDS).  A read
 // with 10^5..10^6 hits thus spreads over more waves at every level instead of serialising
 // ~10 levels on one wave.
+#ifndef SORT_CAP
 #define SORT_CAP 512
+#endif
+#ifndef SORT_LDS_WAVES
 #define SORT_LDS_WAVES 4
+#endif
 struct SortTask { u64 start; u32 n; u32 depth; };
 
 // block-aggregated append (one atomic per list and block)

@@ -71,6 +71,16 @@ __device__ __forceinline__ u64 rot_key(u64 v)
 	return ((u64)hi << 32) | lo;
 }
 
+// wave-uniform values the compiler cannot prove uniform (loaded from memory): pinning them to
+// SGPRs turns the sort's control flow into scalar branches and its index arithmetic into SALU
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// element of a uniform lane as a scalar
+__device__ __forceinline__ u32 lane_get(u32 v, int l) { return (u32)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ u64 lane_get(u64 v, int l)
+{
+	return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, l);
+}
 // data written by some lanes of this wave is re-read by other lanes
 __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
@@ -96,7 +106,7 @@ __device__ __forceinline__ int lane_partition(KT& key, u32& val, int lo, int hi,
 	const bool in = lane >= lo && lane < hi;
 	const bool ge = in && key >= pk;
 	const bool le = in && key <= pk;
-	const u64 mL = __ballot(ge), mR = __ballot(le);
+	const u64 mL = __builtin_amdgcn_ballot_w64(ge), mR = __builtin_amdgcn_ballot_w64(le);
 	const int cL = __popcll(mL), cR = __popcll(mR);
 	const int rankL = __builtin_amdgcn_mbcnt_hi((u32)(mL >> 32), __builtin_amdgcn_mbcnt_lo((u32)mL, 0));
 	const int belowR = __builtin_amdgcn_mbcnt_hi((u32)(mR >> 32), __builtin_amdgcn_mbcnt_lo((u32)mR, 0));
@@ -104,7 +114,7 @@ __device__ __forceinline__ int lane_partition(KT& key, u32& val, int lo, int hi,
 	const int idxL = __builtin_amdgcn_ds_permute((ge ? rankL : 63) << 2, lane);
 	const int idxR = __builtin_amdgcn_ds_permute((le ? rankR : 63) << 2, lane);
 	const int nPairs = cL < cR ? cL : cR;
-	const int K = __popcll(__ballot(lane < nPairs && idxL < idxR));	// l_k < r_k is monotone in k
+	const int K = __popcll(__builtin_amdgcn_ballot_w64(lane < nPairs && idxL < idxR));	// l_k < r_k is monotone in k
 	const int partL = __builtin_amdgcn_ds_bpermute((ge ? rankL : lane) << 2, idxR);
 	const int partR = __builtin_amdgcn_ds_bpermute((le ? rankR : lane) << 2, idxL);
 	int src = lane;
@@ -123,6 +133,7 @@ template <class KT>
 __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int depth, int* stk)
 {
 	const int lane = threadIdx.x & 63;
+	first = uni(first); n = uni(n); depth = uni(depth);
 	KT key = lane < n ? K[first + lane] : (KT)0;
 	u32 val = lane < n ? V[first + lane] : 0u;
 	// pending segments: the smaller part is continued, the larger one waits (only if it is
@@ -145,14 +156,17 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 				break;
 			}
 			--d;
+			// a, b are scalars: the three pivot candidates and the swap of the median into
+			// position a go through v_readlane and selects, no LDS round trip
 			const int mid = a + (b - a) / 2;
-			const KT ka = shflk(key, a + 1), kb = shflk(key, mid), kc = shflk(key, b - 1);
+			const KT ka = lane_get(key, a + 1), kb = lane_get(key, mid), kc = lane_get(key, b - 1);
 			const int m3 = median3(ka, kb, kc);
 			const int pick = m3 == 0 ? a + 1 : (m3 == 1 ? mid : b - 1);
 			const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
-			const int src = lane == a ? pick : (lane == pick ? a : lane);
-			key = shflk(key, src);
-			val = __shfl(val, src);
+			const KT k0 = lane_get(key, a);
+			const u32 v0 = lane_get(val, a), vp = lane_get(val, pick);
+			key = lane == a ? pk : (lane == pick ? k0 : key);
+			val = lane == a ? vp : (lane == pick ? v0 : val);
 			const int cut = lane_partition(key, val, a + 1, b, pk);
 			int oa, ob;
 			if (cut - a < b - cut) { oa = cut; ob = b; b = cut; }
@@ -230,9 +244,10 @@ template <class KT, class PT>
 __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last, PT* posL, PT* posR)
 {
 	const int lane = threadIdx.x & 63;
+	first = uni(first); last = uni(last);
 	const int mid = first + (last - first) / 2;
 	const KT ka = K[first + 1], kb = K[mid], kc = K[last - 1];
-	const int m3 = median3(ka, kb, kc);
+	const int m3 = uni(median3(ka, kb, kc));
 	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
 	const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
 	if (lane == 0)
@@ -252,7 +267,7 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 		KT k0 = K[base + t + lane], k1 = K[base + t + 64 + lane], k2 = K[base + t + 128 + lane], k3 = K[base + t + 192 + lane];
 #define FG_TILE(kk, off) { \
 		const bool ge = kk >= pk, le = kk <= pk; \
-		const u64 mL = __ballot(ge), mR = __ballot(le); \
+		const u64 mL = __builtin_amdgcn_ballot_w64(ge), mR = __builtin_amdgcn_ballot_w64(le); \
 		if (ge) posL[cL + __popcll(mL & below)] = (PT)(t + off + lane); \
 		if (le) posR[cR + __popcll(mR & below)] = (PT)(t + off + lane); \
 		cL += __popcll(mL); cR += __popcll(mR); }
@@ -264,7 +279,7 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 		const bool valid = i < m;
 		const KT kk = valid ? K[base + i] : (KT)0;
 		const bool ge = valid && kk >= pk, le = valid && kk <= pk;
-		const u64 mL = __ballot(ge), mR = __ballot(le);
+		const u64 mL = __builtin_amdgcn_ballot_w64(ge), mR = __builtin_amdgcn_ballot_w64(le);
 		if (ge) posL[cL + __popcll(mL & below)] = (PT)i;
 		if (le) posR[cR + __popcll(mR & below)] = (PT)i;
 		cL += __popcll(mL); cR += __popcll(mR);
@@ -280,7 +295,7 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 		const int a = valid ? (int)posL[kq] : 0;
 		const int b = valid ? (int)posR[cR - 1 - kq] : 0;
 		const bool sw = valid && a < b;
-		const u64 ms = __ballot(sw);
+		const u64 ms = __builtin_amdgcn_ballot_w64(sw);
 		if (sw)
 		{
 			const KT xa = K[base + a], xb = K[base + b];
@@ -289,12 +304,12 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 			K[base + b] = xa; V[base + b] = ya;
 		}
 		nSwap += __popcll(ms);
-		if (ms != __ballot(valid)) break;	// l_k < r_k is monotone in k
+		if (ms != __builtin_amdgcn_ballot_w64(valid)) break;	// l_k < r_k is monotone in k
 	}
 	wave_mem_fence();
 	const int lK1 = (nSwap < cL) ? (int)posL[nSwap] : 0x7fffffff;
 	const int rK = (nSwap >= 1) ? (int)posR[cR - nSwap] : m;
-	return base + (lK1 < rK ? lK1 : rK);
+	return uni(base + (lK1 < rK ? lK1 : rK));
 }
 
 // Same partition, streamed: the two pointers advance in chunks of <= 64 from both ends
@@ -307,9 +322,10 @@ template <class KT>
 __device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int last)
 {
 	const int lane = threadIdx.x & 63;
+	first = uni(first); last = uni(last);
 	const int mid = first + (last - first) / 2;
 	const KT ka = K[first + 1], kb = K[mid], kc = K[last - 1];
-	const int m3 = median3(ka, kb, kc);
+	const int m3 = uni(median3(ka, kb, kc));
 	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
 	const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
 	wave_mem_fence();
@@ -331,7 +347,7 @@ __device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int la
 		if (valid) { kL = K[iL]; vL = V[iL]; kR = K[iR]; vR = V[iR]; }
 		const bool geL = valid && kL >= pk;
 		const bool leR = valid && kR <= pk;
-		const u64 mL = __ballot(geL), mR = __ballot(leR);
+		const u64 mL = __builtin_amdgcn_ballot_w64(geL), mR = __builtin_amdgcn_ballot_w64(leR);
 		const int cL = __popcll(mL), cR = __popcll(mR);
 		const int m = cL < cR ? cL : cR;
 		if (m > 0)
@@ -349,8 +365,8 @@ __device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int la
 				K[dst] = kR; V[dst] = vR;
 			}
 			const int lastL = nth_set_bit(mL, m - 1), lastR = nth_set_bit(mR, m - 1);
-			f = f + lastL + 1;
-			l = l - 1 - lastR;
+			f = uni(f + lastL + 1);
+			l = uni(l - 1 - lastR);
 		}
 		else
 		{
@@ -365,7 +381,7 @@ __device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int la
 	const int cutLane = lane_partition(key, val, 0, W, pk);
 	if (lane < W && (key != key0 || val != val0)) { K[f + lane] = key; V[f + lane] = val; }
 	wave_mem_fence();
-	return f + cutLane;
+	return uni(f + cutLane);
 }
 
 
@@ -377,6 +393,7 @@ template <class KT, class PT>
 __device__ __forceinline__ void wave_sort(KT* K, u32* V, int n, PT* posL, PT* posR, int* stk, int* sstk,
 										  int first0 = 0, int depth0 = -1)
 {
+	n = uni(n); first0 = uni(first0); depth0 = uni(depth0);
 	if (n < 2) return;
 	const int lane = threadIdx.x & 63;
 	int sp = 0;
@@ -410,7 +427,7 @@ __device__ __forceinline__ void wave_sort(KT* K, u32* V, int n, PT* posL, PT* po
 			continue;
 		}
 		if (sp == 0) break;
-		depth = stk[--sp]; last = stk[--sp]; first = stk[--sp];
+		depth = uni(stk[--sp]); last = uni(stk[--sp]); first = uni(stk[--sp]);
 	}
 	wave_mem_fence();
 }

@@ -24,7 +24,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflyegpu.so")
+# FLYE_GPU_LIB: another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("FLYE_GPU_LIB") or os.path.join(_HERE, "lib", "libflyegpu.so")
 
 REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4"),
                       ("cur_end", "<i4"), ("cur_len", "<i4"), ("ext_begin", "<i4"),

@@ -637,6 +637,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 	size_t detected = 0;
 
 	size_t gEnd = 0;
+	bool tieInQuery = false;	// FO_STATS: equal (extId, curPos) keys inside a group that reaches the DP
 	const size_t nh = S.hits.size();
 	while (gEnd < nh)
 	{
@@ -668,6 +669,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 		}
 		++counters[2];
 		counters[3] += M.size();
+		for (size_t t = 1; t < M.size(); ++t) if (M[t].cur == M[t - 1].cur) { tieInQuery = true; break; }
 
 		const int32_t n = (int32_t)M.size();
 		S.score.assign(n, 0);
@@ -815,6 +817,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 		}
 	}
 	for (auto& w : wnd) if (w.range > 0) stats.push_back(w.div);
+	counters[7] += tieInQuery;
 }
 
 } // namespace
@@ -869,8 +872,9 @@ int fo_overlaps(fo_ctx* h, const fg_detector_params* P, const u32* queryIds, u32
 	for (auto& a : cnt) { c.cntKmers += a[0]; c.cntHits += a[1]; c.cntGroups += a[2]; c.cntDp += a[3]; }
 	if (getenv("FO_STATS"))
 	{
-		u64 st[3] = {0, 0, 0};
-		for (auto& a : cnt) { st[0] += a[4]; st[1] += a[5]; st[2] += a[6]; }
+		u64 st[4] = {0, 0, 0, 0};
+		for (auto& a : cnt) { st[0] += a[4]; st[1] += a[5]; st[2] += a[6]; st[3] += a[7]; }
+		fprintf(stderr, "queries with tied (extId, curPos) keys inside a chained group: %llu of %u\n", (unsigned long long)st[3], nq);
 		fprintf(stderr, "look-back: %.2f candidates scanned per DP element; %.2f%% of elements scan > 16, %.2f%% > 64\n",
 				(double)st[0] / std::max<u64>(1, c.cntDp), 100.0 * st[1] / std::max<u64>(1, c.cntDp), 100.0 * st[2] / std::max<u64>(1, c.cntDp));
 	}
