@@ -289,7 +289,8 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT*
 	const int lane = threadIdx.x & 63;
 	const u32 ti = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
 	if (ti >= nTasks) return;
-	const SortTask t = tasks[ti];
+	SortTask t = tasks[ti];
+	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
 	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	SortTask c0{0, 0, 0}, c1{0, 0, 0};
@@ -335,7 +336,8 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	if (nTasks > taskCap) nTasks = taskCap;
 	const u32 ti = blockIdx.x * SORT_LDS_WAVES + wv;
 	if (ti >= nTasks) return;
-	const SortTask t = tasks[ti];
+	SortTask t = tasks[ti];
+	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
 	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	const int n = (int)t.n;

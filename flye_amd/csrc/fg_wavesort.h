@@ -337,42 +337,52 @@ __device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int la
 	}
 	wave_mem_fence();
 	int f = first + 1, l = last;	// untouched window [f, l)
+	// The loads of the next window are issued BEFORE the stores of the current one (they touch
+	// disjoint elements: stores land in the consumed zones, loads come from the untouched
+	// window): memory operations retire in order on this counter, so a load issued behind a
+	// store would put the store's round trip on the serial chain as well.
+	int wl = (l - f) / 2 < 64 ? (l - f) / 2 : 64;
+	KT kL = 0, kR = 0; u32 vL = 0, vR = 0;
+	if (l - f > 63 && lane < wl) { kL = K[f + lane]; vL = V[f + lane]; kR = K[l - 1 - lane]; vR = V[l - 1 - lane]; }
 	while (l - f > 63)
 	{
-		const int W = l - f;
-		const int wl = W / 2 < 64 ? W / 2 : 64;	// W >= 64 here
 		const bool valid = lane < wl;
-		const int iL = f + lane, iR = l - 1 - lane;
-		KT kL = 0, kR = 0; u32 vL = 0, vR = 0;
-		if (valid) { kL = K[iL]; vL = V[iL]; kR = K[iR]; vR = V[iR]; }
 		const bool geL = valid && kL >= pk;
 		const bool leR = valid && kR <= pk;
 		const u64 mL = __builtin_amdgcn_ballot_w64(geL), mR = __builtin_amdgcn_ballot_w64(leR);
 		const int cL = __popcll(mL), cR = __popcll(mR);
 		const int m = cL < cR ? cL : cR;
+		int nf = f, nl = l;
+		int dstL = 0, dstR = 0;
+		bool stL = false, stR = false;
 		if (m > 0)
 		{
-			const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-			const int rankL = __popcll(mL & below), rankR = __popcll(mR & below);
-			if (geL && rankL < m)
-			{
-				const int dst = l - 1 - nth_set_bit(mR, rankL);
-				K[dst] = kL; V[dst] = vL;
-			}
-			if (leR && rankR < m)
-			{
-				const int dst = f + nth_set_bit(mL, rankR);
-				K[dst] = kR; V[dst] = vR;
-			}
-			const int lastL = nth_set_bit(mL, m - 1), lastR = nth_set_bit(mR, m - 1);
-			f = uni(f + lastL + 1);
-			l = uni(l - 1 - lastR);
+			// stop lists through the LDS crossbar (as lane_partition): lane r learns the lane of
+			// the r-th left stop and of the r-th right stop (counted from its window's outer end)
+			const int rankL = __builtin_amdgcn_mbcnt_hi((u32)(mL >> 32), __builtin_amdgcn_mbcnt_lo((u32)mL, 0));
+			const int rankR = __builtin_amdgcn_mbcnt_hi((u32)(mR >> 32), __builtin_amdgcn_mbcnt_lo((u32)mR, 0));
+			const int idxL = __builtin_amdgcn_ds_permute((geL ? rankL : 63) << 2, lane);
+			const int idxR = __builtin_amdgcn_ds_permute((leR ? rankR : 63) << 2, lane);
+			stL = geL && rankL < m;
+			stR = leR && rankR < m;
+			dstL = l - 1 - __builtin_amdgcn_ds_bpermute((stL ? rankL : lane) << 2, idxR);
+			dstR = f + __builtin_amdgcn_ds_bpermute((stR ? rankR : lane) << 2, idxL);
+			const int lastL = __builtin_amdgcn_readlane(idxL, uni(m - 1)), lastR = __builtin_amdgcn_readlane(idxR, uni(m - 1));
+			nf = f + lastL + 1;
+			nl = l - 1 - lastR;
 		}
 		else
 		{
-			if (cL == 0) f += wl;
-			if (cR == 0) l -= wl;
+			if (cL == 0) nf += wl;
+			if (cR == 0) nl -= wl;
 		}
+		const int nwl = (nl - nf) / 2 < 64 ? (nl - nf) / 2 : 64;
+		KT nkL = 0, nkR = 0; u32 nvL = 0, nvR = 0;
+		if (nl - nf > 63 && lane < nwl) { nkL = K[nf + lane]; nvL = V[nf + lane]; nkR = K[nl - 1 - lane]; nvR = V[nl - 1 - lane]; }
+		if (stL) { K[dstL] = kL; V[dstL] = vL; }
+		if (stR) { K[dstR] = kR; V[dstR] = vR; }
+		f = nf; l = nl; wl = nwl;
+		kL = nkL; vL = nvL; kR = nkR; vR = nvR;
 	}
 	const int W = l - f;
 	KT key = lane < W ? K[f + lane] : (KT)0;
