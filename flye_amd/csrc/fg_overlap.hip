@@ -236,19 +236,23 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 #endif
 struct SortTask { u64 start; u32 n; u32 depth; };
 
-// block-aggregated append (one atomic per list and block)
+// block-aggregated append (one atomic per list and block).  Lists: big (one wave per task in
+// k_sort_level), wide (> wideMin elements: a whole workgroup per task, k_sort_wide), small
+// (<= SORT_CAP: k_sort_lds).  counts: [0] big, [1] small, [2] wide.
 __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTask* __restrict__ big,
+										   SortTask* __restrict__ wide, u32 wideMin,
 										   SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
 {
-	__shared__ u32 wcnt[2][WG / 64];
-	__shared__ u32 base[2];
+	__shared__ u32 wcnt[3][WG / 64];
+	__shared__ u32 base[3];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const bool isBig = valid && t.n > SORT_CAP;
+	const bool isWide = valid && t.n > wideMin && t.n > SORT_CAP;
+	const bool isBig = valid && t.n > SORT_CAP && !isWide;
 	const bool isSmall = valid && t.n >= 2 && t.n <= SORT_CAP;
-	const u64 mB = __ballot(isBig), mS = __ballot(isSmall);
-	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mB); wcnt[1][wv] = (u32)__popcll(mS); }
+	const u64 mB = __ballot(isBig), mS = __ballot(isSmall), mW = __ballot(isWide);
+	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mB); wcnt[1][wv] = (u32)__popcll(mS); wcnt[2][wv] = (u32)__popcll(mW); }
 	__syncthreads();
-	if (threadIdx.x < 2)
+	if (threadIdx.x < 3)
 	{
 		u32 tot = 0;
 		for (int i = 0; i < WG / 64; ++i) tot += wcnt[threadIdx.x][i];
@@ -256,9 +260,10 @@ __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTa
 	}
 	__syncthreads();
 	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	u32 oB = base[0], oS = base[1];
-	for (int i = 0; i < wv; ++i) { oB += wcnt[0][i]; oS += wcnt[1][i]; }
+	u32 oB = base[0], oS = base[1], oW = base[2];
+	for (int i = 0; i < wv; ++i) { oB += wcnt[0][i]; oS += wcnt[1][i]; oW += wcnt[2][i]; }
 	if (isBig) big[oB + __popcll(mB & below)] = t;
+	if (isWide) wide[oW + __popcll(mW & below)] = t;
 	if (isSmall)
 	{
 		const u32 slot = oS + __popcll(mS & below);
@@ -268,6 +273,7 @@ __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTa
 }
 
 __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __restrict__ big,
+							SortTask* __restrict__ wide, u32 wideMin,
 							SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
 {
 	const u32 q = blockIdx.x * WG + threadIdx.x;
@@ -277,7 +283,37 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 		const u64 n = hitOff[q + 1] - hitOff[q];
 		t.start = hitOff[q]; t.n = (u32)n; t.depth = n >= 2 ? 2 * fgsort::floor_log2_((int)n) : 0;
 	}
-	sort_route(t, q < nq, big, small, smallCap, counts);
+	sort_route(t, q < nq, big, wide, wideMin, small, smallCap, counts);
+}
+
+// a workgroup of SORT_WIDE_WAVES waves per task: one partition of a huge piece
+#define SORT_WIDE_WAVES 8
+template <class KT>
+__global__ void __launch_bounds__(SORT_WIDE_WAVES * 64)
+k_sort_wide(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hitKey,
+			u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
+			SortTask* __restrict__ children)
+{
+	__shared__ int shm[2 * SORT_WIDE_WAVES];
+	const u32 ti = blockIdx.x;
+	if (ti >= nTasks) return;
+	SortTask t = tasks[ti];
+	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
+	KT* K = hitKey + t.start;
+	u32* V = hitVal + t.start;
+	SortTask c0{0, 0, 0}, c1{0, 0, 0};
+	if (t.depth == 0)
+	{
+		if (threadIdx.x == 0) { wsort::PtrAcc<KT> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+	}
+	else
+	{
+		const int cut = wsort::partition_cf_block<KT, SORT_WIDE_WAVES>(K, V, (int)t.n, posScratch + t.start,
+																	   posScratch + nHits + t.start, shm);
+		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
+		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
+	}
+	if (threadIdx.x == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
 }
 
 // one wave per task: one partition (or the depth-limit heapsort); children to slots 2i, 2i+1
@@ -304,7 +340,7 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT*
 		// the closed form has no serial chain
 		const int cut = t.n <= streamMax
 			? wsort::partition_stream<KT>(K, V, 0, (int)t.n)
-			: wsort::partition_big<KT, u32>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+			: wsort::partition_cf<KT>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
 		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
 		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
 	}
@@ -312,12 +348,13 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT*
 }
 
 __global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildren, SortTask* __restrict__ big,
+							 SortTask* __restrict__ wide, u32 wideMin,
 							 SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
 {
 	const u32 i = blockIdx.x * WG + threadIdx.x;
 	SortTask t{0, 0, 0};
 	if (i < nChildren) t = children[i];
-	sort_route(t, i < nChildren, big, small, smallCap, counts);
+	sort_route(t, i < nChildren, big, wide, wideMin, small, smallCap, counts);
 }
 
 template <class KT>
@@ -527,26 +564,46 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	const u64 bigCap = nHits / SORT_CAP + nSeg + 16;
 	c->dTmp32.reserve(2 * nHits + 2);
 	c->dSortTasks.reserve((size_t)smallCap * sizeof(SortTask));
-	c->dSortBig.reserve((size_t)(4 * bigCap) * sizeof(SortTask));
+	c->dSortBig.reserve((size_t)(6 * bigCap) * sizeof(SortTask));
 	c->dListCnt.reserve(4);
 	SortTask* smallT = (SortTask*)c->dSortTasks.p;
 	SortTask* bigA = (SortTask*)c->dSortBig.p;
 	SortTask* bigB = bigA + bigCap;
 	SortTask* kids = bigB + bigCap;	// 2 * bigCap
-	const u32 streamMax = getenv("FG_SORT_STREAM_MAX") ? (u32)atoi(getenv("FG_SORT_STREAM_MAX")) : 32768u;
-	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 8, s));
+	SortTask* wideA = kids + 2 * bigCap;
+	SortTask* wideB = wideA + bigCap;
+	const u32 streamMax = getenv("FG_SORT_STREAM_MAX") ? (u32)atoi(getenv("FG_SORT_STREAM_MAX")) : 8192u;
+	const u32 wideMin = getenv("FG_SORT_WIDE_MIN") ? (u32)atoi(getenv("FG_SORT_WIDE_MIN")) : 16384u;
+	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 12, s));
 	{ ScopedK t(c->timer, "k_sort_level");
-	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, bigA, smallT, smallCap, c->dListCnt.p); }
-	u32 nBig = fetchScalar(c, c->dListCnt.p);
-	while (nBig)
+	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, bigA, wideA, wideMin, smallT, smallCap,
+						 c->dListCnt.p); }
+	u32 cnt[3];
+	auto fetchCounts = [&]()
+	{
+		HIP_CHECK(hipMemcpyAsync(cnt, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipStreamSynchronize(s));
+	};
+	fetchCounts();
+	u32 nBig = cnt[0], nWide = cnt[2];
+	while (nBig || nWide)
 	{
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p + 2, 0, 4, s));
 		ScopedK t(c->timer, "k_sort_level");
-		hipLaunchKernelGGL(k_sort_level<KT>, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits, kids,
-						   streamMax);
-		hipLaunchKernelGGL(k_sort_route, (2 * nBig + WG - 1) / WG, WG, 0, s, kids, 2 * nBig, bigB, smallT, smallCap, c->dListCnt.p);
-		nBig = fetchScalar(c, c->dListCnt.p);
+		if (nWide)	// the long poles first
+			hipLaunchKernelGGL(k_sort_wide<KT>, nWide, SORT_WIDE_WAVES * 64, 0, s, wideA, nWide, dK, dV, c->dTmp32.p, nHits,
+							   kids + 2 * (size_t)nBig);
+		if (nBig)
+			hipLaunchKernelGGL(k_sort_level<KT>, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits,
+							   kids, streamMax);
+		const u32 nKids = 2 * (nBig + nWide);
+		hipLaunchKernelGGL(k_sort_route, (nKids + WG - 1) / WG, WG, 0, s, kids, nKids, bigB, wideB, wideMin, smallT, smallCap,
+						   c->dListCnt.p);
+		fetchCounts();
+		nBig = cnt[0]; nWide = cnt[2];
 		std::swap(bigA, bigB);
+		std::swap(wideA, wideB);
 	}
 	const u32 nTasks = fetchScalar(c, c->dListCnt.p + 1);
 	if (nTasks > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};

@@ -312,6 +312,374 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 	return uni(base + (lK1 < rK ? lK1 : rK));
 }
 
+// The same closed form without any serial chain, for one big segment in global memory.
+// Phase 1 counts the stops per 64-element tile (running prefixes F_t, P_t of left / right
+// stops, nothing else is stored, so the loads of many tiles are in flight together).  With
+// f(p) = #left stops below p and g(p) = #right stops at or above p, l_k < r_k holds iff some
+// p has f(p) >= k and g(p) >= k, hence K = max_p min(f(p), g(p)); f rises and g falls, so the
+// maximum sits in the tile where they cross.  Phase 3 lists only the 2K stops that swap,
+// phase 4 swaps pair k = (l_k, r_k); no iteration of either depends on another.
+// sL / sR: >= (last - first) entries each (lists in front, tile prefixes behind the middle).
+template <class KT>
+__device__ __forceinline__ int partition_cf(KT* K, u32* V, int first, int last, u32* sL, u32* sR)
+{
+	const int lane = threadIdx.x & 63;
+	first = uni(first); last = uni(last);
+	const int mid = first + (last - first) / 2;
+	const KT ka = K[first + 1], kb = K[mid], kc = K[last - 1];
+	const int m3 = uni(median3(ka, kb, kc));
+	const int pick = m3 == 0 ? first + 1 : (m3 == 1 ? mid : last - 1);
+	const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
+	if (lane == 0)
+	{
+		const KT k0 = K[first]; const u32 v0 = V[first]; const u32 vp = V[pick];
+		K[first] = pk; V[first] = vp;
+		K[pick] = k0; V[pick] = v0;
+	}
+	wave_mem_fence();
+	const int base = first + 1;
+	const int m = last - base;
+	const int T = (m + 63) >> 6;
+	const KT* Kb = K + base;
+	u32* pfL = sL + (m >> 1) + 2;	// the lists hold K <= m/2 entries (2K distinct positions)
+	u32* pfR = sR + (m >> 1) + 2;
+
+	// ---- phase 1: tile prefixes ----
+	int totL = 0, totR = 0;
+	for (int t0 = 0; t0 < T; t0 += 64)
+	{
+		int myL = 0, myR = 0;
+		for (int tt = 0; tt < 64 && t0 + tt < T; tt += 8)
+		{
+			KT kk[8];
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int i = (t0 + tt + u) * 64 + lane;
+				kk[u] = i < m ? Kb[i] : (KT)0;
+			}
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int i = (t0 + tt + u) * 64 + lane;
+				const bool valid = i < m;
+				const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk[u] >= pk);
+				const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk[u] <= pk);
+				if (lane == tt + u) { myL = totL; myR = totR; }
+				totL += __popcll(mL); totR += __popcll(mR);
+			}
+		}
+		if (t0 + lane < T) { pfL[t0 + lane] = (u32)myL; pfR[t0 + lane] = (u32)myR; }
+	}
+	if (lane == 0) { pfL[T] = (u32)totL; pfR[T] = (u32)totR; }
+	wave_mem_fence();
+
+	// largest tile index t in [0, T] for which pred(t) holds (pred true on a prefix, true at 0)
+	auto last_true = [&](auto pred) -> int
+	{
+		int res = 0;
+		for (int t0 = 0; t0 <= T; t0 += 64)
+		{
+			const int t = t0 + lane;
+			const int c = __popcll(__builtin_amdgcn_ballot_w64(t <= T && pred(t)));
+			if (c > 0) res = t0 + c - 1;
+			if (c < 64) break;
+		}
+		return res;
+	};
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+
+	// ---- phase 2: K and the cut ----
+	int Kp;
+	{
+		const int ts = last_true([&](int t) { return (int)pfL[t] <= totR - (int)pfR[t]; });
+		const int i = ts * 64 + lane;
+		const bool valid = ts < T && i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk >= pk);
+		const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk <= pk);
+		const int Ft = uni((int)pfL[ts]), Gt = totR - uni((int)pfR[ts]);
+		const int f = Ft + __popcll(mL & below), g = Gt - __popcll(mR & below);
+		int v = valid ? (f < g ? f : g) : 0;
+		if (lane == 0 && ts < T)	// position just behind the tile
+		{
+			const int fn = (int)pfL[ts + 1], gn = totR - (int)pfR[ts + 1];
+			const int vn = fn < gn ? fn : gn;
+			// lane 0's own candidate is p = tile start: f = Ft <= Gt = g, value Ft, never above vn's
+			// competitors' maximum unless it is the maximum itself; keep both
+			v = v > vn ? v : vn;
+		}
+		for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = v > w ? v : w; }
+		Kp = uni(v);
+	}
+	int lK1 = 0x7fffffff, rK = m;
+	if (Kp < totL)
+	{
+		const int tl = last_true([&](int t) { return t < T && (int)pfL[t] <= Kp; });
+		const int i = tl * 64 + lane;
+		const bool valid = i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk >= pk);
+		lK1 = tl * 64 + nth_set_bit(mL, Kp - uni((int)pfL[tl]));
+	}
+	if (Kp >= 1)
+	{
+		const int idx = totR - Kp;	// 0-based index from the left of r_K among the right stops
+		const int tr = last_true([&](int t) { return t < T && (int)pfR[t] <= idx; });
+		const int i = tr * 64 + lane;
+		const bool valid = i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk <= pk);
+		rK = tr * 64 + nth_set_bit(mR, idx - uni((int)pfR[tr]));
+	}
+	const int cut = base + (lK1 < rK ? lK1 : rK);
+
+	// ---- phase 3: the 2K stops that swap ----
+	if (Kp > 0)
+	{
+		const int firstR = totR - Kp;
+		for (int t0 = 0; t0 < T; t0 += 8)
+		{
+			KT kk[8]; int fl[8], fr[8];
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int t = t0 + u;
+				const int i = t * 64 + lane;
+				kk[u] = (t < T && i < m) ? Kb[i] : (KT)0;
+				fl[u] = t < T ? (int)pfL[t] : 0x7fffffff;
+				fr[u] = t < T ? (int)pfR[t + 1] : 0;
+			}
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int t = t0 + u;
+				const int i = t * 64 + lane;
+				const bool valid = t < T && i < m;
+				const int Fl = uni(fl[u]), Fr1 = uni(fr[u]);
+				if (Fl < Kp)	// some left stop of this tile has rank < K
+				{
+					const bool ge = valid && kk[u] >= pk;
+					const u64 mL = __builtin_amdgcn_ballot_w64(ge);
+					const int r = Fl + __popcll(mL & below);
+					if (ge && r < Kp) sL[r] = (u32)i;
+				}
+				if (Fr1 > firstR)	// some right stop of this tile is among the last K
+				{
+					const bool le = valid && kk[u] <= pk;
+					const u64 mR = __builtin_amdgcn_ballot_w64(le);
+					const int r = Fr1 - __popcll(mR) + __popcll(mR & below);
+					if (le && r >= firstR) sR[r - firstR] = (u32)i;
+				}
+			}
+		}
+		wave_mem_fence();
+		// ---- phase 4: swap pair k = (l_k, r_k), k = 1..K ----
+		for (int k0 = 0; k0 < Kp; k0 += 128)
+		{
+			const int q0 = k0 + lane, q1 = k0 + 64 + lane;
+			const bool s0 = q0 < Kp, s1 = q1 < Kp;
+			const int a0 = s0 ? (int)sL[q0] : 0, b0 = s0 ? (int)sR[Kp - 1 - q0] : 0;
+			const int a1 = s1 ? (int)sL[q1] : 0, b1 = s1 ? (int)sR[Kp - 1 - q1] : 0;
+			KT xa0 = 0, xb0 = 0, xa1 = 0, xb1 = 0; u32 ya0 = 0, yb0 = 0, ya1 = 0, yb1 = 0;
+			if (s0) { xa0 = Kb[a0]; xb0 = Kb[b0]; ya0 = V[base + a0]; yb0 = V[base + b0]; }
+			if (s1) { xa1 = Kb[a1]; xb1 = Kb[b1]; ya1 = V[base + a1]; yb1 = V[base + b1]; }
+			if (s0) { K[base + a0] = xb0; V[base + a0] = yb0; K[base + b0] = xa0; V[base + b0] = ya0; }
+			if (s1) { K[base + a1] = xb1; V[base + a1] = yb1; K[base + b1] = xa1; V[base + b1] = ya1; }
+		}
+	}
+	wave_mem_fence();
+	return uni(cut);
+}
+
+// partition_cf by a whole workgroup of WW waves on one huge segment [0, n): the tiles of phases
+// 1 and 3 and the pairs of phase 4 are dealt to the waves, phase 2 is computed by every wave.
+// shm: >= 2 * WW ints of LDS.  All threads of the block must call.
+template <class KT, int WW>
+__device__ __forceinline__ int partition_cf_block(KT* K, u32* V, int n, u32* sL, u32* sR, int* shm)
+{
+	const int lane = threadIdx.x & 63;
+	const int wv = uni((int)(threadIdx.x >> 6));
+	n = uni(n);
+	const int mid = n / 2;
+	const KT ka = K[1], kb = K[mid], kc = K[n - 1];
+	const int m3 = uni(median3(ka, kb, kc));
+	const int pick = m3 == 0 ? 1 : (m3 == 1 ? mid : n - 1);
+	const KT pk = m3 == 0 ? ka : (m3 == 1 ? kb : kc);
+	__syncthreads();	// every wave has read the candidates
+	if (threadIdx.x == 0)
+	{
+		const KT k0 = K[0]; const u32 v0 = V[0]; const u32 vp = V[pick];
+		K[0] = pk; V[0] = vp;
+		K[pick] = k0; V[pick] = v0;
+	}
+	__syncthreads();
+	const int base = 1;
+	const int m = n - base;
+	const int T = (m + 63) >> 6;
+	const KT* Kb = K + base;
+	u32* pfL = sL + (m >> 1) + 2;
+	u32* pfR = sR + (m >> 1) + 2;
+
+	// ---- phase 1: tile prefixes, a contiguous range of tiles per wave ----
+	const int per = (((T + WW - 1) / WW) + 63) & ~63;
+	const int tBeg = wv * per < T ? wv * per : T;
+	const int tEnd = tBeg + per < T ? tBeg + per : T;
+	int locL = 0, locR = 0;
+	for (int t0 = tBeg; t0 < tEnd; t0 += 64)
+	{
+		int myL = 0, myR = 0;
+		for (int tt = 0; tt < 64 && t0 + tt < tEnd; tt += 8)
+		{
+			KT kk[8];
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int i = (t0 + tt + u) * 64 + lane;
+				kk[u] = (t0 + tt + u < tEnd && i < m) ? Kb[i] : (KT)0;
+			}
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int i = (t0 + tt + u) * 64 + lane;
+				const bool valid = t0 + tt + u < tEnd && i < m;
+				const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk[u] >= pk);
+				const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk[u] <= pk);
+				if (lane == tt + u) { myL = locL; myR = locR; }
+				locL += __popcll(mL); locR += __popcll(mR);
+			}
+		}
+		if (t0 + lane < tEnd) { pfL[t0 + lane] = (u32)myL; pfR[t0 + lane] = (u32)myR; }
+	}
+	if (lane == 0) { shm[wv] = locL; shm[WW + wv] = locR; }
+	__syncthreads();
+	int offL = 0, offR = 0, totL = 0, totR = 0;
+	for (int w = 0; w < WW; ++w)
+	{
+		const int a = shm[w], b = shm[WW + w];
+		if (w < wv) { offL += a; offR += b; }
+		totL += a; totR += b;
+	}
+	offL = uni(offL); offR = uni(offR); totL = uni(totL); totR = uni(totR);
+	for (int t = tBeg + lane; t < tEnd; t += 64) { pfL[t] += (u32)offL; pfR[t] += (u32)offR; }
+	if (threadIdx.x == 0) { pfL[T] = (u32)totL; pfR[T] = (u32)totR; }
+	__syncthreads();
+
+	auto last_true = [&](auto pred) -> int
+	{
+		int res = 0;
+		for (int t0 = 0; t0 <= T; t0 += 64)
+		{
+			const int t = t0 + lane;
+			const int c = __popcll(__builtin_amdgcn_ballot_w64(t <= T && pred(t)));
+			if (c > 0) res = t0 + c - 1;
+			if (c < 64) break;
+		}
+		return res;
+	};
+	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+
+	// ---- phase 2 (every wave): K and the cut ----
+	int Kp;
+	{
+		const int ts = last_true([&](int t) { return (int)pfL[t] <= totR - (int)pfR[t]; });
+		const int i = ts * 64 + lane;
+		const bool valid = ts < T && i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk >= pk);
+		const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk <= pk);
+		const int Ft = uni((int)pfL[ts]), Gt = totR - uni((int)pfR[ts]);
+		const int f = Ft + __popcll(mL & below), g = Gt - __popcll(mR & below);
+		int v = valid ? (f < g ? f : g) : 0;
+		if (lane == 0 && ts < T)
+		{
+			const int fn = (int)pfL[ts + 1], gn = totR - (int)pfR[ts + 1];
+			const int vn = fn < gn ? fn : gn;
+			v = v > vn ? v : vn;
+		}
+		for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = v > w ? v : w; }
+		Kp = uni(v);
+	}
+	int lK1 = 0x7fffffff, rK = m;
+	if (Kp < totL)
+	{
+		const int tl = last_true([&](int t) { return t < T && (int)pfL[t] <= Kp; });
+		const int i = tl * 64 + lane;
+		const bool valid = i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mL = __builtin_amdgcn_ballot_w64(valid && kk >= pk);
+		lK1 = tl * 64 + nth_set_bit(mL, Kp - uni((int)pfL[tl]));
+	}
+	if (Kp >= 1)
+	{
+		const int idx = totR - Kp;
+		const int tr = last_true([&](int t) { return t < T && (int)pfR[t] <= idx; });
+		const int i = tr * 64 + lane;
+		const bool valid = i < m;
+		const KT kk = valid ? Kb[i] : (KT)0;
+		const u64 mR = __builtin_amdgcn_ballot_w64(valid && kk <= pk);
+		rK = tr * 64 + nth_set_bit(mR, idx - uni((int)pfR[tr]));
+	}
+	const int cut = base + (lK1 < rK ? lK1 : rK);
+
+	// ---- phase 3: the 2K stops that swap, groups of 8 tiles dealt round-robin ----
+	if (Kp > 0)
+	{
+		const int firstR = totR - Kp;
+		for (int t0 = wv * 8; t0 < T; t0 += 8 * WW)
+		{
+			KT kk[8]; int fl[8], fr[8];
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int t = t0 + u;
+				const int i = t * 64 + lane;
+				kk[u] = (t < T && i < m) ? Kb[i] : (KT)0;
+				fl[u] = t < T ? (int)pfL[t] : 0x7fffffff;
+				fr[u] = t < T ? (int)pfR[t + 1] : 0;
+			}
+	#pragma unroll
+			for (int u = 0; u < 8; ++u)
+			{
+				const int t = t0 + u;
+				const int i = t * 64 + lane;
+				const bool valid = t < T && i < m;
+				const int Fl = uni(fl[u]), Fr1 = uni(fr[u]);
+				if (Fl < Kp)
+				{
+					const bool ge = valid && kk[u] >= pk;
+					const u64 mL = __builtin_amdgcn_ballot_w64(ge);
+					const int r = Fl + __popcll(mL & below);
+					if (ge && r < Kp) sL[r] = (u32)i;
+				}
+				if (Fr1 > firstR)
+				{
+					const bool le = valid && kk[u] <= pk;
+					const u64 mR = __builtin_amdgcn_ballot_w64(le);
+					const int r = Fr1 - __popcll(mR) + __popcll(mR & below);
+					if (le && r >= firstR) sR[r - firstR] = (u32)i;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// ---- phase 4: swap pair k = (l_k, r_k) ----
+	for (int k0 = wv * 128; k0 < Kp; k0 += 128 * WW)
+	{
+		const int q0 = k0 + lane, q1 = k0 + 64 + lane;
+		const bool s0 = q0 < Kp, s1 = q1 < Kp;
+		const int a0 = s0 ? (int)sL[q0] : 0, b0 = s0 ? (int)sR[Kp - 1 - q0] : 0;
+		const int a1 = s1 ? (int)sL[q1] : 0, b1 = s1 ? (int)sR[Kp - 1 - q1] : 0;
+		KT xa0 = 0, xb0 = 0, xa1 = 0, xb1 = 0; u32 ya0 = 0, yb0 = 0, ya1 = 0, yb1 = 0;
+		if (s0) { xa0 = Kb[a0]; xb0 = Kb[b0]; ya0 = V[base + a0]; yb0 = V[base + b0]; }
+		if (s1) { xa1 = Kb[a1]; xb1 = Kb[b1]; ya1 = V[base + a1]; yb1 = V[base + b1]; }
+		if (s0) { K[base + a0] = xb0; V[base + a0] = yb0; K[base + b0] = xa0; V[base + b0] = ya0; }
+		if (s1) { K[base + a1] = xb1; V[base + a1] = yb1; K[base + b1] = xa1; V[base + b1] = ya1; }
+	}
+	__syncthreads();
+	return uni(cut);
+}
+
 // Same partition, streamed: the two pointers advance in chunks of <= 64 from both ends
 // (every element is read once, only swapped elements are written: ~18 B per element against
 // ~30 B for the closed form), at the price of a serial dependence between the chunks.

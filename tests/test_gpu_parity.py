@@ -228,11 +228,14 @@ def _median3_killer(n):
     return a
 
 
-def test_device_sort_equals_std_sort(built):
+@pytest.mark.parametrize("stream_max", [None, 600, 10 ** 9])
+def test_device_sort_equals_std_sort(built, monkeypatch, stream_max):
     """k_sort_hits on its own: tie-heavy, patterned and adversarial inputs must come
     out in exactly the permutation std::sort produces (heapsort fallback included)."""
     from flye_amd import gpu
     from oracle import oracle as O
+    if stream_max is not None:      # which partition form the level kernel uses above the LDS piece size
+        monkeypatch.setenv("FG_SORT_STREAM_MAX", str(stream_max))
     rng = np.random.default_rng(7)
     segs = []
     for n in list(range(0, 70)) + [100, 128, 129, 191, 192, 193, 255, 257, 1000, 4097, 20000, 70000]:
