@@ -706,6 +706,19 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 				if (!extSorted && curNext - curPrev > P.max_jump) break;
 			}
 			counters[4] += scanned; counters[5] += scanned > 16; counters[6] += scanned > 64;
+			if (getenv("FO_STATS2"))
+			{
+				static std::atomic<unsigned long long> H[8];	// candidate steps at depth <=8,<=16,<=32,<=64,<=128,<=256,more
+				int lim[7] = {8, 16, 32, 64, 128, 256, 1 << 30}, prev = 0;
+				for (int b = 0; b < 7; ++b) { int hi = std::min(scanned, lim[b]); if (hi > prev) H[b] += hi - prev; prev = std::max(prev, hi); }
+				H[7] += 1;
+				if ((H[7] & 0xFFFFF) == 0)
+				{
+					fprintf(stderr, "steps by depth:");
+					for (int b = 0; b < 7; ++b) fprintf(stderr, " %.2f", (double)H[b] / H[7]);
+					fprintf(stderr, " per element\n");
+				}
+			}
 			S.score[i] = std::max(maxScore, k);
 			if (maxScore > k) S.back[i] = maxId;
 		}
