@@ -97,7 +97,8 @@ def main():
     t_upload = time.time() - t0
     vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
     st = vi.build(cfg)
-    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
+    # --min-ovlp of the pipeline driver (N90 rule) = Parameters::minimumOverlap of the assemble stage
+    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=min_ovlp)
     queries = dist.shard_queries(rs.n, rank, world)
     my_bp = int(rs.length[(queries // 2).astype(np.int64)].sum())
 
@@ -172,7 +173,7 @@ def main():
                      "upload_s": round(t_upload, 3), "index_entries": int(st["index_entries"])},
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(rs, cfg, vi, queries, args.cpu_sample_bp)
+            line["cpu_baseline"] = cpu_baseline(rs, cfg, vi, queries, args.cpu_sample_bp, min_ovlp)
             # parity on the timed workload itself: the sample's records must match
             line["cpu_baseline"]["sample_records_identical"] = bool(line["cpu_baseline"].pop("_same")(res))
         print(json.dumps(line), flush=True)
@@ -180,7 +181,7 @@ def main():
         td.destroy_process_group()
 
 
-def cpu_baseline(rs, cfg, vi, queries, sample_bp):
+def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
     """The CPU oracle on this host's cores over a bounded sample of the same queries
     against the same index (imported from the device, so the CPU does not spend
     minutes rebuilding it).  Checker/baseline only -- never the measured product."""
@@ -194,7 +195,7 @@ def cpu_baseline(rs, cfg, vi, queries, sample_bp):
     n = int(np.searchsorted(np.cumsum(lens), sample_bp)) + 1
     n = max(1, min(n, len(queries)))
     sample = queries[:n]
-    p = O.detector_params(cfg)
+    p = O.detector_params(cfg, min_overlap=min_ovlp)
     t0 = time.perf_counter()
     ores = o.overlaps(p, sample, threads=cores)
     dt = time.perf_counter() - t0
