@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--scale", type=float, default=None, help="genome scale (default = --gpus)")
     ap.add_argument("--cpu-sample-bp", type=float, default=250e6)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-reference", action="store_true",
+                    help="also time the compiled reference itself (oracle/_ref/ref_dumper: its own index build "
+                         "+ getSeqOverlaps over a bounded prefix of the queries); minutes, off by default")
+    ap.add_argument("--cpu-reference-threads", type=int, default=0, help="0 = the CPUs this process may use")
     args = ap.parse_args()
 
     import torch
@@ -176,9 +180,25 @@ def main():
             line["cpu_baseline"] = cpu_baseline(rs, cfg, vi, queries, args.cpu_sample_bp, min_ovlp)
             # parity on the timed workload itself: the sample's records must match
             line["cpu_baseline"]["sample_records_identical"] = bool(line["cpu_baseline"].pop("_same")(res))
+            if args.cpu_reference:
+                line["cpu_reference"] = cpu_reference(rs, preset, min_ovlp, queries, res,
+                                                      args.cpu_reference_threads or effective_cpus())
         print(json.dumps(line), flush=True)
     if world > 1:
         td.destroy_process_group()
+
+
+def effective_cpus() -> int:
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota
+    (the GPU box shows 256 hardware threads but grants 16 CPUs' worth of time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
@@ -186,7 +206,7 @@ def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
     against the same index (imported from the device, so the CPU does not spend
     minutes rebuilding it).  Checker/baseline only -- never the measured product."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = effective_cpus()
     o = O.Oracle(int(cfg["kmer_size"]), threads=cores)
     o.set_reads(rs)
     ex = vi.export()
@@ -211,6 +231,37 @@ def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
     return {"value": round(ores.query_bp / dt / 1e9, 6), "unit": "Gbp/s", "cores": cores, "kind": "port",
             "sample": f"first {n} query reads ({ores.query_bp} bp) of the same workload, same index, "
                       f"{dt:.2f} s wall", "_same": same}
+
+
+def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=30e6):
+    """The reference itself (Flye 2.8.1 sources compiled by oracle/Makefile, unmodified) on this
+    host: reads written as FASTA, its own countKmers + buildIndexUnevenCoverage over ALL reads,
+    then getSeqOverlaps for a prefix of the forward reads through its processInParallel.
+    Checker/baseline only."""
+    import tempfile
+    from flye_amd import config
+    from oracle import oracle as O
+    if not O.have_ref():
+        return {"error": "oracle/_ref/ref_dumper not built"}
+    lens = rs.length[(queries // 2).astype(np.int64)]
+    n = max(1, min(int(np.searchsorted(np.cumsum(lens), sample_bp)) + 1, len(queries)))
+    if not np.array_equal(queries[:n], np.arange(0, 2 * n, 2)):
+        return {"error": "reference run needs the rank-0, N=1 query order"}
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, "reads.fasta")
+        ov = os.path.join(tmp, "ovlp.txt")
+        rs.write_fasta(fa)
+        t0 = time.perf_counter()
+        info = O.run_ref(fa, params_string=config.params_string(preset), threads=threads, min_read_len=0,
+                         min_overlap=min_ovlp, query_limit=n, ovlp_out=ov)
+        wall = time.perf_counter() - t0
+        ref_lines = [l.strip() for l in open(ov) if l.strip() and not l.startswith("#")]
+    end = int(gres.query_off[n])
+    same = gres.lines()[:end] == ref_lines if end < 400000 else None
+    return {"value": round(info["queried_bp"] / info["overlap_s"] / 1e9, 6), "unit": "Gbp/s", "cores": threads,
+            "kind": "reference", "overlap_s": info["overlap_s"], "index_s": info["index_s"], "load_s": info["load_s"],
+            "sample": f"first {n} forward reads ({info['queried_bp']} bp); index built by the reference over all reads; "
+                      f"{wall:.1f} s wall in total", "gpu_records_identical_to_reference": same}
 
 
 if __name__ == "__main__":

@@ -111,7 +111,9 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 	append3(n >= minSize && n > 0, false, false, (u32)g, list, list, list, counts);
 }
 
-#define FIN_CAP_S 256		// <= : LDS, 4 groups per block; larger groups run on global scratch.
+#ifndef FIN_CAP_S
+#define FIN_CAP_S 256
+#endif		// <= : LDS, 4 groups per block; larger groups run on global scratch.
 #define FIN_BT_CAP 0	// > 0: global-scratch groups up to this size backtrack in LDS (measured slower: occupancy)
 // (Measured: staging 257..1024-hit groups in LDS at 2 waves per block, or > 2048-hit groups at
 // one wave per block, is slower than global scratch -- the occupancy lost costs more than the
