@@ -73,6 +73,11 @@ class OverlapBatch(C.Structure):
                 ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
 
 
+class BridgeStats(C.Structure):
+    _fields_ = [("device_calls", C.c_uint64), ("reads_computed", C.c_uint64), ("requests", C.c_uint64),
+                ("cache_hits", C.c_uint64), ("cached_overlaps", C.c_uint64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("seconds", C.c_double), ("launches", C.c_uint64)]
 
@@ -108,6 +113,17 @@ def load_library():
         L.fg_release_batch.argtypes = [C.POINTER(OverlapBatch)]
         L.fg_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
         L.fg_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        # include/flye_gpu_bridge.h
+        L.fgb_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(DetectorParams), C.c_uint32, C.c_uint32]
+        L.fgb_destroy.argtypes = [C.c_void_p]
+        L.fgb_lazy.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.fgb_quick.argtypes = [C.c_void_p, C.c_uint32, C.c_int32, C.c_uint8, C.c_void_p, C.c_uint64,
+                                C.POINTER(C.c_uint64)]
+        L.fgb_prefetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fgb_set_divergence_threshold.argtypes = [C.c_void_p, C.c_float]
+        L.fgb_divergence_stats.restype = C.c_uint64
+        L.fgb_divergence_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.fgb_get_stats.argtypes = [C.c_void_p, C.POINTER(BridgeStats)]
         _LIB = L
     return _LIB
 
@@ -424,3 +440,65 @@ class OverlapContainer:
         base = np.float32(self._mean_true_ovlp_div) if isRelative else np.float32(0.0)
         self.det.p.max_divergence = float(base + np.float32(threshold))
         return self.det.p.max_divergence
+
+
+class BatchingOverlapContainer:
+    """Binding of include/flye_gpu_bridge.h: the native batch scheduler that turns the
+    one-read-at-a-time calls of Flye's worker threads (overlap.cpp:518-574) into device
+    batches.  Every method may be called from any number of Python threads (ctypes releases
+    the GIL for the duration of a call); the context must not be used directly meanwhile."""
+
+    def __init__(self, det: OverlapDetector, max_batch=4096, linger_us=200):
+        self.ctx = det.ctx
+        self.L = det.ctx.L
+        h = C.c_void_p()
+        self.ctx._check(self.L.fgb_create(C.byref(h), self.ctx.h, C.byref(det.p), max_batch, linger_us))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.fgb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def lazySeqOverlaps(self, readId: int) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_uint64()
+        self.ctx._check(self.L.fgb_lazy(self.h, int(readId), C.byref(p), C.byref(n)))
+        if not n.value:
+            return np.empty(0, REC_DTYPE)
+        buf = (C.c_uint8 * (n.value * REC_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=REC_DTYPE).copy()
+
+    def quickSeqOverlaps(self, readId: int, maxOverlaps: int = 0, forceLocal: bool = False) -> np.ndarray:
+        n = C.c_uint64()
+        cap = 4096
+        while True:
+            out = np.empty(cap, REC_DTYPE)
+            self.ctx._check(self.L.fgb_quick(self.h, int(readId), maxOverlaps, int(bool(forceLocal)),
+                                             out.ctypes.data, cap, C.byref(n)))
+            if n.value <= cap:
+                return out[:n.value]
+            cap = int(n.value)
+
+    def prefetch(self, readIds):
+        q = np.ascontiguousarray(readIds, dtype=np.uint32)
+        self.ctx._check(self.L.fgb_prefetch(self.h, q.ctypes.data, len(q)))
+
+    def setDivergenceThreshold(self, maxDivergence: float):
+        self.ctx._check(self.L.fgb_set_divergence_threshold(self.h, float(maxDivergence)))
+
+    def divergenceStats(self) -> np.ndarray:
+        n = self.L.fgb_divergence_stats(self.h, None, 0)
+        out = np.empty(n, np.float32)
+        self.L.fgb_divergence_stats(self.h, out.ctypes.data, n)
+        return out
+
+    def stats(self) -> dict:
+        st = BridgeStats()
+        self.L.fgb_get_stats(self.h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}

@@ -1,0 +1,75 @@
+/* flye_gpu_bridge.h -- host-side batch scheduler above the C ABI of flye_gpu.h
+ * (SURVEY.md §8f, N1).
+ *
+ * Flye asks for overlaps ONE read at a time from up to --threads worker threads
+ * (OverlapContainer::lazySeqOverlaps / quickSeqOverlaps, src/sequence/overlap.cpp:
+ * 518-574, called from extender.cpp, chimera.cpp, repeat_graph.cpp,
+ * read_aligner.cpp); the device wants batches, and an fg_ctx may only be used by
+ * one host thread at a time.  This container is what OverlapContainer's query
+ * side becomes: any number of threads call fgb_lazy / fgb_quick concurrently and
+ * block; ONE dispatcher thread owns the fg_ctx, drains the pending requests every
+ * `linger_us` microseconds (or as soon as `max_batch` are waiting) into one
+ * fg_overlaps call per (max_overlaps, force_local) class, stores the lazily
+ * computed lists exactly as overlap.cpp:555-571 does (forward list + its
+ * OverlapRange::complement()ed twin, overlap.h:118-147) and wakes the callers.
+ * A per-read result is a pure function of (read, index, parameters), so the
+ * batching is invisible in the results.
+ *
+ * All functions are thread safe unless noted.  Status codes are flye_gpu.h's.
+ */
+#ifndef FLYE_GPU_BRIDGE_H
+#define FLYE_GPU_BRIDGE_H
+
+#include "flye_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fgb_container fgb_container;
+
+/* ctx must have its index built and must not be used directly by the caller while
+ * the container lives.  params is copied (max_divergence can be changed later with
+ * fgb_set_divergence_threshold).  keep_alignment / partition_bad_mappings are
+ * passed through to fg_overlaps; their extra arrays are not cached (FG_ERR_UNSUPPORTED). */
+int  fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params* params,
+                uint32_t max_batch, uint32_t linger_us);
+void fgb_destroy(fgb_container* c);
+
+/* OverlapContainer::lazySeqOverlaps(readId) (overlap.cpp:528-574): maxOverlaps = 0,
+ * forceLocal = false, computed for the forward id, cached, the reverse-complement
+ * id served by the complemented list.  *recs stays valid until fgb_destroy. */
+int fgb_lazy(fgb_container* c, uint32_t read_id, const struct fg_overlap_rec** recs, uint64_t* n);
+
+/* OverlapContainer::quickSeqOverlaps(readId, maxOverlaps, forceLocal) (overlap.cpp:
+ * 518-526): not cached.  Writes at most cap records, *n is the full count. */
+int fgb_quick(fgb_container* c, uint32_t read_id, int32_t max_overlaps, uint8_t force_local,
+              struct fg_overlap_rec* out, uint64_t cap, uint64_t* n);
+
+/* Hint: these reads will be asked for (e.g. Extender::assembleDisjointigs warming the
+ * cache over all forward reads, extender.cpp:363-382).  Returns at once; the lists are
+ * computed in batches of max_batch by the dispatcher. */
+int fgb_prefetch(fgb_container* c, const uint32_t* read_ids, uint32_t n);
+
+/* OverlapContainer::setDivergenceThreshold's effect on the detector (overlap.cpp:
+ * 820-827): later device calls use the new gate; cached lists are kept, as in the
+ * reference. */
+int fgb_set_divergence_threshold(fgb_container* c, float max_divergence);
+
+/* OvlpDivStats values appended so far (overlap.h:283-309): copies min(cap, count)
+ * floats, returns the count. */
+uint64_t fgb_divergence_stats(fgb_container* c, float* out, uint64_t cap);
+
+struct fgb_stats {
+	uint64_t device_calls;     /* fg_overlaps calls made */
+	uint64_t reads_computed;   /* query ids sent to the device */
+	uint64_t requests;         /* fgb_lazy + fgb_quick calls */
+	uint64_t cache_hits;       /* fgb_lazy calls answered without waiting for the device */
+	uint64_t cached_overlaps;  /* OverlapContainer::indexSize() */
+};
+void fgb_get_stats(fgb_container* c, struct fgb_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -7,10 +7,10 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "flye_gpu.h")).read()
+def _declared(header="flye_gpu.h", prefix="fg_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fg_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z_]+)\s*\(", text)))
 
 
 def test_header_symbols_exported(built):
@@ -22,6 +22,12 @@ def test_header_symbols_exported(built):
         assert hasattr(lib, n), f"{n} declared in include/flye_gpu.h but not exported"
     assert set(gpu.ABI_SYMBOLS) <= set(names)
     assert lib.fg_abi_version() == 2
+    # the batch scheduler above the ABI (include/flye_gpu_bridge.h)
+    bridge = _declared("flye_gpu_bridge.h", "fgb_")
+    assert len(bridge) >= 8
+    for n in bridge:
+        assert hasattr(lib, n), f"{n} declared in include/flye_gpu_bridge.h but not exported"
+    assert lib.fgb_create(None, None, None, 0, 0) == -3
 
 
 def test_error_strings_and_argument_checks(built):

@@ -284,6 +284,65 @@ def test_container_mirror_and_divergence_threshold(built, golden_cases):
     assert one.tobytes() == f.tobytes()
 
 
+def test_batching_container_under_threads(built):
+    """include/flye_gpu_bridge.h: 16 threads ask for one read at a time (lazy, quick, both
+    strands, repeats), the dispatcher turns that into a few device batches; every list equals
+    the direct fg_overlaps result and lazy reverse ids get the complemented forward list."""
+    import threading
+    from flye_amd import config, gpu, synth
+    rs = synth.simulate(seed=31, genome_len=60_000, coverage=25, kind="pb_raw", n_tandems=30).filter_min_len(1000)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = 0.3
+    allq = np.arange(0, 2 * rs.n, dtype=np.uint32)
+    direct = det.getSeqOverlapsBatch(allq)                      # lazy class: maxOverlaps 0, not local
+    direct_q = det.getSeqOverlapsBatch(allq, forceLocal=True, maxOverlaps=5)
+    direct_stats = np.sort(det.getSeqOverlapsBatch(allq[::2]).stats)
+    oc = gpu.BatchingOverlapContainer(det, max_batch=64, linger_us=300)
+    rng = np.random.default_rng(3)
+    work = [rng.permutation(np.concatenate([allq, allq[: rs.n]])) for _ in range(16)]
+    errors = []
+
+    def worker(t):
+        try:
+            for j, rid in enumerate(work[t]):
+                rid = int(rid)
+                got = oc.lazySeqOverlaps(rid)
+                want = direct.of(rid & ~1)
+                if rid & 1:
+                    want = gpu.complement(want)
+                assert got.tobytes() == want.tobytes(), ("lazy", rid)
+                if (j + t) % 7 == 0:
+                    q = oc.quickSeqOverlaps(rid, 5, True)
+                    assert q.tobytes() == direct_q.of(rid).tobytes(), ("quick", rid)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    oc.prefetch(allq[:40])
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    stc = oc.stats()
+    n_lazy = sum(len(w) for w in work)
+    assert stc["requests"] >= n_lazy
+    assert stc["cached_overlaps"] == sum(len(direct.of(i)) for i in range(0, 2 * rs.n, 2))
+    # every forward read went to the device once for the lazy class, in far fewer calls than reads
+    quick_reads = stc["reads_computed"] - rs.n
+    assert quick_reads >= 0 and stc["device_calls"] < (rs.n + quick_reads) // 2
+    assert stc["cache_hits"] > n_lazy // 2
+    # OvlpDivStats: the lazy class contributes exactly the values of one pass over the forward reads
+    lazy_stats = oc.divergenceStats()
+    assert len(lazy_stats) >= len(direct_stats)
+    oc.setDivergenceThreshold(0.05)
+    tight = oc.quickSeqOverlaps(0)
+    det.p.max_divergence = 0.05
+    oc.close()
+    assert tight.tobytes() == det.getSeqOverlapsBatch(np.array([0], np.uint32)).recs.tobytes()
+
+
 def test_internal_chunking_is_invisible(built, monkeypatch):
     """fg_overlaps cuts big batches into chunks bounded by k-mers / seed hits (and halves a
     chunk whose hits exceed the budget); results must not depend on the cut."""
