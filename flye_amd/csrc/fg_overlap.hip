@@ -360,9 +360,11 @@ __global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildre
 template <class KT>
 __global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
 k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount, u32 taskCap,
-		   KT* __restrict__ hitKey, u32* __restrict__ hitVal)
+		   KT* __restrict__ hitKey, u32* __restrict__ hitVal, int curBits, u64 narrowMax,
+		   u32* __restrict__ posScratch, u64 nHits)
 {
-	__shared__ KT sK[SORT_LDS_WAVES][SORT_CAP];
+	// the LDS piece always holds 32-bit keys (12 B per hit with the position scratch)
+	__shared__ u32 sK[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ u32 sV[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ unsigned short sPL[SORT_LDS_WAVES][SORT_CAP], sPR[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ int stack[SORT_LDS_WAVES][3 * 40];
@@ -378,13 +380,59 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	const int n = (int)t.n;
-	for (int i = lane; i < n; i += 64) { sK[wv][i] = K[i]; sV[wv][i] = V[i]; }
-	wsort::wave_mem_fence();
-	wsort::wave_sort<KT, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
-	for (int i = lane; i < n; i += 64) { K[i] = sK[wv][i]; V[i] = sV[wv][i]; }
+	if (sizeof(KT) == 4)
+	{
+		for (int i = lane; i < n; i += 64) { sK[wv][i] = (u32)K[i]; sV[wv][i] = V[i]; }
+		wsort::wave_mem_fence();
+		wsort::wave_sort<u32, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+		for (int i = lane; i < n; i += 64) { K[i] = (KT)sK[wv][i]; V[i] = sV[wv][i]; }
+		return;
+	}
+	// 64-bit keys (extId << 32 | curPos): a piece of <= 512 hits of one query usually spans few
+	// target records, so (extId << curBits | curPos) minus the piece's minimum fits 32 bits -- an
+	// order-preserving map, hence the same permutation at the 32-bit kernel's cost.  curBits = 0
+	// (arbitrary keys, fg_debug_sort_pairs): the keys themselves are tried.
+	const u64 lowMask = curBits ? (1ULL << curBits) - 1 : 0;
+	u64 pk[SORT_CAP / 64];
+	u64 mn = ~0ULL, mx = 0;
+#pragma unroll
+	for (int j = 0; j < SORT_CAP / 64; ++j)
+	{
+		const int i = j * 64 + lane;
+		u64 k64 = i < n ? (u64)K[i] : 0;
+		if (curBits) k64 = ((k64 >> 32) << curBits) | (k64 & 0xFFFFFFFFULL);
+		pk[j] = k64;
+		if (i < n) { mn = k64 < mn ? k64 : mn; mx = k64 > mx ? k64 : mx; }
+	}
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		const u64 a = wsort::shflk(mn, lane ^ o), b = wsort::shflk(mx, lane ^ o);
+		mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+	}
+	mn = fg_uni(mn); mx = fg_uni(mx);
+	if (mx - mn <= narrowMax)
+	{
+#pragma unroll
+		for (int j = 0; j < SORT_CAP / 64; ++j)
+		{
+			const int i = j * 64 + lane;
+			if (i < n) { sK[wv][i] = (u32)(pk[j] - mn); sV[wv][i] = V[i]; }
+		}
+		wsort::wave_mem_fence();
+		wsort::wave_sort<u32, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+		for (int i = lane; i < n; i += 64)
+		{
+			const u64 p = (u64)sK[wv][i] + mn;
+			K[i] = (KT)(curBits ? (((p >> curBits) << 32) | (p & lowMask)) : p);
+			V[i] = sV[wv][i];
+		}
+		return;
+	}
+	// a piece that spans more than 2^32 packed keys: sorted where it lies, in global memory
+	wsort::wave_sort<KT, u32>(K, V, n, posScratch + t.start, posScratch + nHits + t.start, stack[wv], small[wv], 0,
+							  (int)t.depth);
 }
 
-// 32-bit sort keys back to extId << 32 | curPos
 __global__ void k_expand_keys(const u32* __restrict__ k32, u64 n, int curBits, u32 firstId, u64* __restrict__ k64)
 {
 	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
@@ -556,7 +604,7 @@ T fetchScalar(fg_ctx* c, const T* dptr)
 
 // std::sort order of each segment [segOff[i], segOff[i+1]) of device arrays K, V
 template <class KT>
-static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* dV, u64 nHits)
+static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* dV, u64 nHits, int curBits = 0)
 {
 	hipStream_t s = c->stream;
 	// pieces are disjoint; even the median-of-3 killer stays far below one task per 8 hits
@@ -611,7 +659,9 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	{
 		ScopedK t(c->timer, "k_sort_lds");
 		hipLaunchKernelGGL(k_sort_lds<KT>, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-						   smallT, c->dListCnt.p + 1, smallCap, dK, dV);
+						   smallT, c->dListCnt.p + 1, smallCap, dK, dV, curBits,
+						   getenv("FG_NARROW_MAX") ? strtoull(getenv("FG_NARROW_MAX"), nullptr, 10) : 0xFFFFFFFFULL,
+						   c->dTmp32.p, nHits);
 	}
 }
 
@@ -692,7 +742,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
-		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits);
+		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits, curBits);
 	}
 	{ ScopedK t(c->timer, "k_group_count");
 	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }

@@ -368,6 +368,13 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
     monkeypatch.setenv("FG_FORCE_KEY64", "1")
     k64 = det.getSeqOverlapsBatch(q, maxOverlaps=11)
     assert (k64.recs.tobytes(), k64.query_off.tobytes(), k64.stats.tobytes()) == base[:3]
+    # ... whose LDS pieces are narrowed to 32 bits relative to the piece's minimum when the piece spans
+    # little enough; force the wide fallback for most / all pieces too
+    for lim in (3_000_000, 0):
+        monkeypatch.setenv("FG_NARROW_MAX", str(lim))
+        wide = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+        assert (wide.recs.tobytes(), wide.query_off.tobytes(), wide.stats.tobytes()) == base[:3], lim
+    monkeypatch.delenv("FG_NARROW_MAX")
     monkeypatch.delenv("FG_FORCE_KEY64")
 
 
