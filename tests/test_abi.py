@@ -95,3 +95,12 @@ def test_c_consumer_runs_on_gpu(built, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "overlaps for 60 reads" in r.stdout
+
+
+def test_graft_entry_build_passes(built):
+    """build() is the driver's "does it build" check: it must succeed on a CPU-only box
+    (a stale assertion in it once outlived an ABI bump)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
