@@ -269,13 +269,17 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	i32* ringS = ring[threadIdx.x >> 6][2];
 	i32 tc = lane < n ? (i32)cur[lane] : 0, te = lane < n ? (i32)ext[lane] : 0;
 	i32 ntc = 64 + lane < n ? (i32)cur[64 + lane] : 0, nte = 64 + lane < n ? (i32)ext[64 + lane] : 0;
-	i32 rs = 0, rb = -1;	// element 0: score 0, no predecessor
-	i32 wc = tc, we = te, ws = 0;	// window for i = 1: only lane 0 (element 0) is meaningful
+	// The results of a tile are not gathered per element: the score window `ws` (and a back
+	// pointer window `wb` shifted along with it) holds elements i-1 .. i-64 on lanes 0 .. 63, so at
+	// a tile boundary the tile's results are the windows read in reverse lane order.
+	i32 rs = 0, rb = -1;
+	i32 wc = tc, we = te, ws = 0, wb = -1;	// window for i = 1: only lane 0 (element 0: score 0, no predecessor) is meaningful
 	for (i32 i = 1; i < n; ++i)
 	{
 		if ((i & 63) == 0)
 		{
 			const i32 tb = i - 64;
+			rs = __shfl(ws, 63 - lane); rb = __shfl(wb, 63 - lane);
 			score[tb + lane] = rs; back[tb + lane] = rb;
 			ringC[(tb + lane) & (DP_RING - 1)] = tc; ringE[(tb + lane) & (DP_RING - 1)] = te; ringS[(tb + lane) & (DP_RING - 1)] = rs;
 			tc = ntc; te = nte;
@@ -306,15 +310,14 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 			i32 cp = wc, ep = we, sj = ws;
 			if (jb != i - 1)
 			{
-				// deeper than the register window: current tile from registers, the previous
-				// DP_RING elements from LDS, anything older from memory (stored by this wave)
+				// deeper than the register window: the previous DP_RING elements from LDS,
+				// anything older from memory (stored by this wave)
+				// (j <= i - 65 < tileBase: never inside the current tile)
 				const i32 tileBase = i & ~63;
-				const i32 inC = __shfl(tc, j & 63), inE = __shfl(te, j & 63), inS = __shfl(rs, j & 63);
 				cp = 0; ep = 0; sj = 0;
 				if (valid)
 				{
-					if (j >= tileBase) { cp = inC; ep = inE; sj = inS; }
-					else if (j >= tileBase - DP_RING)
+					if (j >= tileBase - DP_RING)
 					{
 						cp = ringC[j & (DP_RING - 1)]; ep = ringE[j & (DP_RING - 1)]; sj = ringS[j & (DP_RING - 1)];
 					}
@@ -351,11 +354,14 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 			if (stopM || ((P.ablate & 1) != 0)) done = true;
 		}
 		const i32 sNew = max(maxScore, k);
-		if (lane == (i & 63)) { rs = sNew; rb = maxScore > k ? maxId : -1; }
 		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
+		wb = wave_shr1(wb, maxScore > k ? maxId : -1);
 	}
 	{
+		// last (partial) tile: element tb + L sits on lane n-1-tb-L of the windows
 		const i32 tb = (n - 1) & ~63;
+		const i32 src = (n - 1 - tb - lane) & 63;
+		rs = __shfl(ws, src); rb = __shfl(wb, src);
 		if (tb + lane < n) { score[tb + lane] = rs; back[tb + lane] = rb; }
 	}
 }
