@@ -1,12 +1,33 @@
 /* Plain-C consumer of the C ABI (include/flye_gpu.h): packs a few reads, builds the solid
  * k-mer index, asks for the overlaps of every forward read and prints them in Flye's
  * OverlapRange::dump order of fields.  Build:
- *   gcc -std=c99 -Iinclude examples/c_abi_demo.c -Lflye_amd/lib -lflyegpu -Wl,-rpath,$PWD/flye_amd/lib -o c_abi_demo
+ *   gcc -std=c99 -pthread -Iinclude examples/c_abi_demo.c -Lflye_amd/lib -lflyegpu -Wl,-rpath,$PWD/flye_amd/lib -o c_abi_demo
+ * Then the same reads are asked for one at a time from 8 threads through the batch scheduler
+ * of include/flye_gpu_bridge.h.
  * Without a GPU it prints the error of fg_create and exits with status 2. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 #include "flye_gpu.h"
+#include "flye_gpu_bridge.h"
+
+/* worker of the second part: asks the batch scheduler for one read at a time, as a Flye
+ * worker thread would (OverlapContainer::lazySeqOverlaps, overlap.cpp:528-574) */
+struct worker_arg { fgb_container* oc; int first, step, n; uint64_t recs; int rc; };
+static void* worker(void* vp)
+{
+	struct worker_arg* a = (struct worker_arg*)vp;
+	int i;
+	for (i = a->first; i < a->n; i += a->step)
+	{
+		const struct fg_overlap_rec* r; uint64_t n;
+		a->rc = fgb_lazy(a->oc, (uint32_t)i, &r, &n);	/* both strands: ids 0 .. 2*NREADS-1 */
+		if (a->rc != FG_OK) return NULL;
+		a->recs += n;
+	}
+	return NULL;
+}
 
 static uint64_t rng_state = 12345;
 static uint32_t rnd(void)
@@ -69,7 +90,31 @@ int main(void)
 			   r->ext_begin, r->ext_end, r->ext_len, r->score, r->seq_divergence);
 	}
 	rc = b.n_recs > 0 ? 0 : 1;
-	fg_release_batch(&b);
+	{
+		/* the same lists through the scheduler: 8 threads, one read per call, both strands;
+		 * a reverse-complement id gets the complemented list of its forward read */
+		enum { NT = 8 };
+		const uint64_t want = 2 * b.n_recs;
+		fgb_container* oc = NULL;
+		struct fgb_stats bs;
+		pthread_t th[NT];
+		struct worker_arg wa[NT];
+		uint64_t got = 0;
+		fg_release_batch(&b);
+		if (fgb_create(&oc, ctx, &p, 32, 200) != FG_OK) { printf("fgb_create failed\n"); return 1; }
+		for (i = 0; i < NT; ++i)
+		{
+			wa[i].oc = oc; wa[i].first = i; wa[i].step = NT; wa[i].n = 2 * NREADS; wa[i].recs = 0; wa[i].rc = FG_OK;
+			pthread_create(&th[i], NULL, worker, &wa[i]);
+		}
+		for (i = 0; i < NT; ++i) { pthread_join(th[i], NULL); got += wa[i].recs; if (wa[i].rc != FG_OK) rc = 1; }
+		fgb_get_stats(oc, &bs);
+		printf("scheduler: %llu overlaps over both strands (expected %llu) from %llu requests in %llu device calls\n",
+			   (unsigned long long)got, (unsigned long long)want, (unsigned long long)bs.requests,
+			   (unsigned long long)bs.device_calls);
+		if (got != want || bs.device_calls >= (uint64_t)NREADS) rc = 1;
+		fgb_destroy(oc);
+	}
 	fg_destroy(ctx);
 	return rc;
 }

@@ -68,7 +68,7 @@ def _build_c_demo(tmp_path):
     import subprocess
     exe = str(tmp_path / "c_abi_demo")
     lib = os.path.join(ROOT, "flye_amd", "lib")
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+    subprocess.run(["gcc", "-std=c99", "-pthread", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + lib, "-lflyegpu",
                     "-Wl,-rpath," + lib, "-o", exe], check=True)
     return exe
@@ -94,7 +94,7 @@ def test_c_consumer_runs_on_gpu(built, tmp_path):
     exe = _build_c_demo(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "overlaps for 60 reads" in r.stdout
+    assert "overlaps for 60 reads" in r.stdout and "scheduler:" in r.stdout
 
 
 def test_graft_entry_build_passes(built):
