@@ -314,15 +314,45 @@ __global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wo
 	const i32 nk = L - k;
 	const u64* w = words + wordOff[r];
 	const uint8_t* fl = flags + kmerOff[r];
-	for (i32 p = threadIdx.x; p < nk; p += WG)
+	// ONE cursor atomic per read: same-address atomics serialise at ~11 ns each, and one per
+	// wave and step (what the compiler's aggregation of a per-element atomicAdd gives) was 3.4 M of
+	// them = 39 of the build's 85 ms.  The emission order is irrelevant (radix sort follows).
+	__shared__ u32 shw[WG / 64];
+	__shared__ u64 shBase;
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	u32 mine = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG) mine += fl[p] ? 1u : 0u;
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+	if (lane == 0) shw[wv] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0)
 	{
-		if (!fl[p]) continue;
-		u64 fw, rv;
-		fg_kmer_pair(w, p, k, fw, rv);
-		const bool flip = rv < fw;
-		const u64 slot = atomicAdd(cursor, 1ULL);
-		ecanon[slot] = flip ? rv : fw;
-		evalue[slot] = ((u64)(2 * r + (flip ? 1 : 0)) << posBits) | (u64)(flip ? L - p - k : p);
+		u32 tot = 0;
+		for (int i = 0; i < WG / 64; ++i) tot += shw[i];
+		shBase = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
+	}
+	__syncthreads();
+	u64 base = shBase;
+	for (i32 p0 = 0; p0 < nk; p0 += WG)
+	{
+		const i32 p = p0 + (i32)threadIdx.x;
+		const bool take = p < nk && fl[p];
+		const u64 m = __ballot(take);
+		__syncthreads();
+		if (lane == 0) shw[wv] = (u32)__popcll(m);
+		__syncthreads();
+		u32 before = 0, tot = 0;
+		for (int i = 0; i < WG / 64; ++i) { const u32 c = shw[i]; if (i < wv) before += c; tot += c; }
+		if (take)
+		{
+			u64 fw, rv;
+			fg_kmer_pair(w, p, k, fw, rv);
+			const bool flip = rv < fw;
+			const u64 slot = base + before + (u64)__popcll(m & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane))));
+			ecanon[slot] = flip ? rv : fw;
+			evalue[slot] = ((u64)(2 * r + (flip ? 1 : 0)) << posBits) | (u64)(flip ? L - p - k : p);
+		}
+		base += tot;
 	}
 }
 
