@@ -68,30 +68,42 @@ __device__ __forceinline__ bool overlap_test(const ChainParams& P, u32 curId, u3
 }
 
 // ---- lists -------------------------------------------------------------------------------
-// block-aggregated append of the calling thread's group to up to three lists: one atomic
-// per list and 256-thread block (same-address atomics serialise at ~30 ns each)
-__device__ __forceinline__ void append3(bool a, bool b, bool c, u32 g, u32* listA, u32* listB, u32* listC,
-										u32* counts)
+// block-aggregated append of the calling thread's LIST_ITEMS consecutive groups to up to two
+// lists: one atomic per list and block of LIST_ITEMS * 256 groups (same-address atomics
+// serialise; the list kernels were bound by exactly these atomics at one per 256 groups)
+#define LIST_ITEMS 8
+__device__ __forceinline__ void append2_multi(const bool (&a)[LIST_ITEMS], const bool (&b)[LIST_ITEMS], u32 g0,
+											  u32* listA, u32* listB, u32* counts)
 {
-	__shared__ u32 wcnt[3][WG / 64];
-	__shared__ u32 base[3];
+	__shared__ u32 wtot[2][WG / 64];
+	__shared__ u32 base[2];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	const u64 mA = __builtin_amdgcn_ballot_w64(a), mB = __builtin_amdgcn_ballot_w64(b), mC = __builtin_amdgcn_ballot_w64(c);
-	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mA); wcnt[1][wv] = (u32)__popcll(mB); wcnt[2][wv] = (u32)__popcll(mC); }
+	u32 cA = 0, cB = 0;
+#pragma unroll
+	for (int t = 0; t < LIST_ITEMS; ++t) { cA += a[t]; cB += b[t]; }
+	u32 iA = cA, iB = cB;	// inclusive scan over the wave
+	for (int o = 1; o < 64; o <<= 1)
+	{
+		const u32 x = __shfl_up(iA, o), y = __shfl_up(iB, o);
+		if (lane >= o) { iA += x; iB += y; }
+	}
+	if (lane == 63) { wtot[0][wv] = iA; wtot[1][wv] = iB; }
 	__syncthreads();
-	if (threadIdx.x < 3)
+	if (threadIdx.x < 2)
 	{
 		u32 t = 0;
-		for (int i = 0; i < WG / 64; ++i) t += wcnt[threadIdx.x][i];
+		for (int i = 0; i < WG / 64; ++i) t += wtot[threadIdx.x][i];
 		base[threadIdx.x] = t ? atomicAdd(&counts[threadIdx.x], t) : 0u;
 	}
 	__syncthreads();
-	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	u32 oA = base[0], oB = base[1], oC = base[2];
-	for (int i = 0; i < wv; ++i) { oA += wcnt[0][i]; oB += wcnt[1][i]; oC += wcnt[2][i]; }
-	if (a) listA[oA + __popcll(mA & below)] = g;
-	if (b) listB[oB + __popcll(mB & below)] = g;
-	if (c) listC[oC + __popcll(mC & below)] = g;
+	u32 oA = base[0] + iA - cA, oB = base[1] + iB - cB;
+	for (int i = 0; i < wv; ++i) { oA += wtot[0][i]; oB += wtot[1][i]; }
+#pragma unroll
+	for (int t = 0; t < LIST_ITEMS; ++t)
+	{
+		if (a[t]) listA[oA++] = g0 + (u32)t;
+		if (b[t]) listB[oB++] = g0 + (u32)t;
+	}
 }
 
 // groups that can still have >= minUnique distinct query positions (unique <= size)
@@ -99,16 +111,26 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primCount,
 							 u32* __restrict__ dpSize)
 {
-	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
-	u64 n = 0;
-	if (g < nGroups)
+	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
+	bool a[LIST_ITEMS], b[LIST_ITEMS];
+	u64 start = g0 < nGroups ? groupStart[g0] : nHits;
+#pragma unroll
+	for (int t = 0; t < LIST_ITEMS; ++t)
 	{
-		primCount[g] = 0;
-		dpSize[g] = 0;
-		const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
-		n = gend - groupStart[g];
+		const u64 g = g0 + t;
+		u64 n = 0;
+		if (g < nGroups)
+		{
+			primCount[g] = 0;
+			dpSize[g] = 0;
+			const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
+			n = gend - start;
+			start = gend;
+		}
+		a[t] = n >= minSize && n > 0;
+		b[t] = false;
 	}
-	append3(n >= minSize && n > 0, false, false, (u32)g, list, list, list, counts);
+	append2_multi(a, b, (u32)g0, list, list, counts);
 }
 
 #ifndef FIN_CAP_S
@@ -122,9 +144,16 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listSmall,
 						  u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
 {
-	const u64 g = (u64)blockIdx.x * WG + threadIdx.x;
-	const u32 n = g < nGroups ? dpSize[g] : 0u;
-	append3(n > 0 && n <= FIN_CAP_S, n > FIN_CAP_S, false, (u32)g, listSmall, listMid, listBig, counts);
+	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
+	bool a[LIST_ITEMS], b[LIST_ITEMS];
+#pragma unroll
+	for (int t = 0; t < LIST_ITEMS; ++t)
+	{
+		const u32 n = g0 + t < nGroups ? dpSize[g0 + t] : 0u;
+		a[t] = n > 0 && n <= FIN_CAP_S;
+		b[t] = n > FIN_CAP_S;
+	}
+	append2_multi(a, b, (u32)g0, listSmall, listMid, counts);
 }
 
 // ---- prep --------------------------------------------------------------------------------
@@ -564,7 +593,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	c->dScore.reserve(nHits + 16); c->dBack.reserve(nHits + 16);
 	c->dTmp32.reserve(4 * nHits + 16);
 	c->dCand.reserve(nHits + 1);
-	const unsigned gridG = (unsigned)((nGroups + WG - 1) / WG);
+	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");
 	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dListSmall.p,
