@@ -136,10 +136,12 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 #ifndef FIN_CAP_S
 #define FIN_CAP_S 256
 #endif		// <= : LDS, 4 groups per block; larger groups run on global scratch.
-#define FIN_BT_CAP 0	// > 0: global-scratch groups up to this size backtrack in LDS (measured slower: occupancy)
-// (Measured: staging 257..1024-hit groups in LDS at 2 waves per block, or > 2048-hit groups at
-// one wave per block, is slower than global scratch -- the occupancy lost costs more than the
-// latency saved.)
+#ifndef FIN_BT_CAP
+#define FIN_BT_CAP 1024	// global-scratch groups up to this size walk their back pointers in LDS
+#endif
+// (Measured at the bench workload: BT cap 512 / 768 / 1024 / 1536 / 2048 -> k_chain_finish<global>
+// 7.0 / 6.2 / 6.1 / 6.4 / 8.0 ms against 7.8 ms with the walk in global memory; staging the SORT
+// of 257..1024-hit groups in LDS as well costs more occupancy than it saves latency.)
 // groups that passed the prefilter, by size class
 __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listSmall,
 						  u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
