@@ -450,6 +450,12 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 			unsigned short* pl = (unsigned short*)(oval + CAP);
 			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + CAP, stack[wv], small[wv]);
 		}
+		else if (BT_CAP > 0 && n <= BT_CAP)
+		{
+			// the walk's LDS (4 B per hit) first serves as the sort's two position lists
+			unsigned short* pl = (unsigned short*)btLds[wv];
+			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + BT_CAP, stack[wv], small[wv]);
+		}
 		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
 	}
 
