@@ -185,7 +185,18 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	const u64* K = hitKey + g0;
 	const u32* V = hitVal + g0;
 
-	// distinct query positions (overlap.cpp:220-235; prevPos starts at 0) and ext span
+	// the lookups that only the survivors need are issued first, so that their round trips overlap
+	// the pass over the hits instead of following it
+	const u32 qrec = query[groupQuery[g]];
+	const u64 k0 = K[0];
+	const u32 extRec = (u32)(k0 >> 32) - P.firstId;
+	const i32 curLen = qLen[qrec >> 1];
+	const i32 extLen = len[extRec >> 1];
+	const i32 maxCur = (i32)(u32)K[n - 1];
+
+	// distinct query positions (overlap.cpp:220-235; prevPos starts at 0) and ext span; groups that
+	// fit the LDS piece are staged on the way
+	const bool inLds = n <= PREP_CAP;
 	u32 uniq = 0;
 	i32 minExt = 0x7fffffff, maxExt = I32_MIN;
 	for (i32 i = lane; i < n; i += 64)
@@ -195,6 +206,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		uniq += (c != pc);
 		const i32 e = (i32)V[i];
 		minExt = min(minExt, e); maxExt = max(maxExt, e);
+		if (inLds) { sCur[wv][i] = c; sExt[wv][i] = (u32)e; }
 	}
 	for (int o = 32; o > 0; o >>= 1)
 	{
@@ -203,11 +215,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		maxExt = max(maxExt, __shfl_xor(maxExt, o));
 	}
 	if ((float)uniq < P.minUnique) return;
-	const u32 qrec = query[groupQuery[g]];
-	const u32 extRec = (u32)(K[0] >> 32) - P.firstId;
-	const i32 curLen = qLen[qrec >> 1];
-	const i32 extLen = len[extRec >> 1];
-	const i32 minCur = (i32)(u32)K[0], maxCur = (i32)(u32)K[n - 1];
+	const i32 minCur = (i32)(u32)k0;
 	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
 	if (P.checkOverhang && !P.forceLocal)
 	{
@@ -219,16 +227,16 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	u32* oc = gCur + g0;
 	u32* oe = gExt + g0;
 	const bool extSorted = extLen > curLen;
-	if (!extSorted)
+	if (inLds)
+	{
+		wsort::wave_mem_fence();
+		if (extSorted)
+			wsort::wave_sort<u32, unsigned short>(sExt[wv], sCur[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv]);
+		for (i32 i = lane; i < n; i += 64) { oc[i] = sCur[wv][i]; oe[i] = sExt[wv][i]; }
+	}
+	else if (!extSorted)
 	{
 		for (i32 i = lane; i < n; i += 64) { oc[i] = (u32)K[i]; oe[i] = V[i]; }
-	}
-	else if (n <= PREP_CAP)
-	{
-		for (i32 i = lane; i < n; i += 64) { sCur[wv][i] = (u32)K[i]; sExt[wv][i] = V[i]; }
-		wsort::wave_mem_fence();
-		wsort::wave_sort<u32, unsigned short>(sExt[wv], sCur[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv]);
-		for (i32 i = lane; i < n; i += 64) { oc[i] = sCur[wv][i]; oe[i] = sExt[wv][i]; }
 	}
 	else
 	{
