@@ -106,8 +106,11 @@ __device__ __forceinline__ void append2_multi(const bool (&a)[LIST_ITEMS], const
 	}
 }
 
-// groups that can still have >= minUnique distinct query positions (unique <= size)
+// groups that can still have >= minUnique distinct query positions (unique <= size) and whose
+// query span reaches minOverlap (the first and last hit of the sorted group give it: overlap.cpp:
+// 244-249 would drop the group anyway, here it never costs k_group_prep a wave)
 __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
+							 const u64* __restrict__ hitKey, i32 minOverlap,
 							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primCount,
 							 u32* __restrict__ dpSize)
 {
@@ -119,15 +122,18 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 	{
 		const u64 g = g0 + t;
 		u64 n = 0;
+		bool ok = false;
 		if (g < nGroups)
 		{
 			primCount[g] = 0;
 			dpSize[g] = 0;
 			const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
 			n = gend - start;
+			if (n >= minSize && n > 0)
+				ok = (i32)(u32)hitKey[gend - 1] - (i32)(u32)hitKey[start] >= minOverlap;
 			start = gend;
 		}
-		a[t] = n >= minSize && n > 0;
+		a[t] = ok;
 		b[t] = false;
 	}
 	append2_multi(a, b, (u32)g0, list, list, counts);
@@ -612,7 +618,8 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");
-	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dListSmall.p,
+	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dHitKey.p,
+						 (i32)p->min_overlap, c->dListSmall.p,
 						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
 	const u32 nPrep = fetchU32(c, c->dListCnt.p);
 	if (!nPrep) return;
