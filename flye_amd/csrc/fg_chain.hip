@@ -110,7 +110,7 @@ __device__ __forceinline__ void append2_multi(const bool (&a)[LIST_ITEMS], const
 // query span reaches minOverlap (the first and last hit of the sorted group give it: overlap.cpp:
 // 244-249 would drop the group anyway, here it never costs k_group_prep a wave)
 __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
-							 const u64* __restrict__ hitKey, i32 minOverlap,
+							 const u32* __restrict__ groupFirstCur, const u32* __restrict__ groupLastCur, i32 minOverlap,
 							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primCount,
 							 u32* __restrict__ dpSize)
 {
@@ -130,7 +130,7 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 			const u64 gend = (g + 1 < nGroups) ? groupStart[g + 1] : nHits;
 			n = gend - start;
 			if (n >= minSize && n > 0)
-				ok = (i32)(u32)hitKey[gend - 1] - (i32)(u32)hitKey[start] >= minOverlap;
+				ok = (i32)groupLastCur[g] - (i32)groupFirstCur[g] >= minOverlap;
 			start = gend;
 		}
 		a[t] = ok;
@@ -167,11 +167,12 @@ __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __re
 // ---- prep --------------------------------------------------------------------------------
 #define PREP_CAP 512
 #define PREP_WAVES 4
+template <class KT>
 __global__ void __launch_bounds__(PREP_WAVES * 64)
 k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 			 const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-			 const u64* __restrict__ hitKey, const u32* __restrict__ hitVal,
+			 HitKeyView<KT> hitKey, const u32* __restrict__ groupExt, const u32* __restrict__ hitVal,
 			 u32* __restrict__ gCur, u32* __restrict__ gExt, u32* __restrict__ gAux /* 4 u32 per hit */,
 			 u32* __restrict__ dpSize)
 {
@@ -188,17 +189,15 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	const u64 g0 = fg_uni(groupStart[g]);
 	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
-	const u64* K = hitKey + g0;
 	const u32* V = hitVal + g0;
 
 	// the lookups that only the survivors need are issued first, so that their round trips overlap
 	// the pass over the hits instead of following it
 	const u32 qrec = query[groupQuery[g]];
-	const u64 k0 = K[0];
-	const u32 extRec = (u32)(k0 >> 32) - P.firstId;
+	const u32 extRec = groupExt[g] - P.firstId;
 	const i32 curLen = qLen[qrec >> 1];
 	const i32 extLen = len[extRec >> 1];
-	const i32 maxCur = (i32)(u32)K[n - 1];
+	const i32 minCur = (i32)hitKey.cur(g0), maxCur = (i32)hitKey.cur(g0 + n - 1);
 
 	// distinct query positions (overlap.cpp:220-235; prevPos starts at 0) and ext span; groups that
 	// fit the LDS piece are staged on the way
@@ -207,8 +206,8 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	i32 minExt = 0x7fffffff, maxExt = I32_MIN;
 	for (i32 i = lane; i < n; i += 64)
 	{
-		const u32 c = (u32)K[i];
-		const u32 pc = i ? (u32)K[i - 1] : 0u;
+		const u32 c = hitKey.cur(g0 + i);
+		const u32 pc = i ? hitKey.cur(g0 + i - 1) : 0u;
 		uniq += (c != pc);
 		const i32 e = (i32)V[i];
 		minExt = min(minExt, e); maxExt = max(maxExt, e);
@@ -221,7 +220,6 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		maxExt = max(maxExt, __shfl_xor(maxExt, o));
 	}
 	if ((float)uniq < P.minUnique) return;
-	const i32 minCur = (i32)(u32)k0;
 	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
 	if (P.checkOverhang && !P.forceLocal)
 	{
@@ -242,11 +240,11 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	}
 	else if (!extSorted)
 	{
-		for (i32 i = lane; i < n; i += 64) { oc[i] = (u32)K[i]; oe[i] = V[i]; }
+		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = V[i]; }
 	}
 	else
 	{
-		for (i32 i = lane; i < n; i += 64) { oc[i] = (u32)K[i]; oe[i] = V[i]; }
+		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = V[i]; }
 		wsort::wave_mem_fence();
 		u32* aux = gAux + 4 * g0;
 		wsort::wave_sort<u32, u32>(oe, oc, n, aux, aux + n, stack[wv], small[wv]);
@@ -284,7 +282,7 @@ __global__ void __launch_bounds__(DP_WAVES * 64)
 k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 		   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-		   const u64* __restrict__ hitKey,
+		   const u32* __restrict__ groupExt,
 		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
 		   i32* __restrict__ gScore, i32* __restrict__ gBack)
 {
@@ -296,7 +294,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
 	const u32 qrec = fg_uni(query[groupQuery[g]]);
-	const u32 extRec = fg_uni((u32)(hitKey[g0] >> 32)) - P.firstId;
+	const u32 extRec = fg_uni(groupExt[g]) - P.firstId;
 	const bool extSorted = fg_uni(len[extRec >> 1]) > fg_uni(qLen[qrec >> 1]);
 	const u32* cur = gCur + g0;
 	const u32* ext = gExt + g0;
@@ -419,7 +417,7 @@ __global__ void __launch_bounds__(FIN_WAVES * 64)
 k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 			   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-			   const u64* __restrict__ hitKey,
+			   const u32* __restrict__ groupExt,
 			   const u32* __restrict__ gCur, const u32* __restrict__ gExt, i32* __restrict__ gScore,
 			   i32* __restrict__ gBack, u32* __restrict__ gAux /* 4 u32 per hit */, int4* __restrict__ cand,
 			   u32* __restrict__ primCount)
@@ -493,7 +491,7 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	// each, since a chain walked in between may have consumed it).
 	const u32 qrec = query[q];
 	const u32 curId = P.qFirstId + qrec;
-	const u32 extId = (u32)(hitKey[g0] >> 32);
+	const u32 extId = groupExt[g];
 	const i32 curLen = qLen[qrec >> 1];
 	const i32 extLen = len[(extId - P.firstId) >> 1];
 	int4* cd = cand + g0;
@@ -588,7 +586,8 @@ u32 fetchU32(fg_ctx* c, const u32* dptr)
 
 // All target groups of the batch -> dPrimFlag[g] = number of primaries (their (first, last,
 // chainLength, score) tuples at the head of the group's dCand region), dDpSize[g]
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits)
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, bool key32,
+				  int curBits)
 {
 	hipStream_t s = c->stream;
 	ChainParams cp;
@@ -618,15 +617,22 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");
-	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dHitKey.p,
-						 (i32)p->min_overlap, c->dListSmall.p,
+	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dGroupFirstCur.p,
+						 c->dGroupLastCur.p, (i32)p->min_overlap, c->dListSmall.p,
 						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
 	const u32 nPrep = fetchU32(c, c->dListCnt.p);
 	if (!nPrep) return;
 	{ ScopedK t(c->timer, "k_group_prep");
-	  hipLaunchKernelGGL(k_group_prep, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
-						 nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dHitKey.p,
-						 c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
+	  if (key32)
+		hipLaunchKernelGGL(k_group_prep<u32>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
+						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
+						   HitKeyView<u32>{c->dHitKey32.p, curBits, c->firstId}, c->dGroupExt.p,
+						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p);
+	  else
+		hipLaunchKernelGGL(k_group_prep<u64>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
+						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
+						   HitKeyView<u64>{c->dHitKey.p, curBits, c->firstId}, c->dGroupExt.p,
+						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_dp_list");
 	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListSmall.p, c->dListDp.p,
@@ -641,12 +647,12 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 			{
 				ScopedK t(c->timer, "k_chain_dp");
 				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
-								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dHitKey.p,
+								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dGroupExt.p,
 								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
 			}
 	}
 #define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
-		qLen, c->dHitKey.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
+		qLen, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
 	if (hc[1])
 	{
 		ScopedK t(c->timer, "k_chain_finish<global>");

@@ -187,6 +187,9 @@ struct fg_ctx {
 	DevBuf<int4> dCand;
 	DevBuf<u64> dGroupStart;	// group boundaries (indices into hits)
 	DevBuf<u32> dGroupQuery;
+	// per group: its target id and the query position of its first and last hit (what the
+	// chaining kernels and the span prefilter need of the sorted keys)
+	DevBuf<u32> dGroupExt, dGroupFirstCur, dGroupLastCur;
 	DevBuf<u32> dTmp32;
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
@@ -218,6 +221,22 @@ __device__ __forceinline__ u64 fg_uni(u64 v)
 	return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) |
 		   (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
+
+// the sorted hit keys, typed at compile time: u64 = (extId << 32 | curPos),
+// u32 = ((extId - firstId) << curBits | curPos)
+template <class KT> struct HitKeyView;
+template <> struct HitKeyView<u64> {
+	const u64* k; int curBits; u32 firstId;
+	__device__ __forceinline__ u32 ext(u64 i) const { return (u32)(k[i] >> 32); }
+	__device__ __forceinline__ u32 ext_raw(u64 i) const { return (u32)(k[i] >> 32); }
+	__device__ __forceinline__ u32 cur(u64 i) const { return (u32)k[i]; }
+};
+template <> struct HitKeyView<u32> {
+	const u32* k; int curBits; u32 firstId;
+	__device__ __forceinline__ u32 ext(u64 i) const { return (k[i] >> curBits) + firstId; }
+	__device__ __forceinline__ u32 ext_raw(u64 i) const { return k[i] >> curBits; }
+	__device__ __forceinline__ u32 cur(u64 i) const { return k[i] & ((1u << curBits) - 1u); }
+};
 
 __device__ __forceinline__ u64 fg_mix(u64 x)
 {
@@ -324,7 +343,8 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits);
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, bool key32,
+				  int curBits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,

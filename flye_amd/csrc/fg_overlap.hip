@@ -433,33 +433,28 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 							  (int)t.depth);
 }
 
-__global__ void k_expand_keys(const u32* __restrict__ k32, u64 n, int curBits, u32 firstId, u64* __restrict__ k64)
-{
-	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
-	if (i >= n) return;
-	const u32 v = k32[i];
-	k64[i] = ((u64)(firstId + (v >> curBits)) << 32) | (v & ((1u << curBits) - 1u));
-}
-
 // ---- target groups ---------------------------------------------------------------------
-__global__ void k_group_count(const u64* __restrict__ hitOff, const u64* __restrict__ hitKey,
-							  u64* __restrict__ groupCnt)
+template <class KT>
+__global__ void k_group_count(const u64* __restrict__ hitOff, HitKeyView<KT> hitKey, u64* __restrict__ groupCnt)
 {
 	__shared__ u32 sh[WG / 64];
 	const u32 q = blockIdx.x;
 	const u64 b = hitOff[q], e = hitOff[q + 1];
 	u32 c = 0;
 	for (u64 i = b + threadIdx.x; i < e; i += WG)
-		c += (i == b) || ((hitKey[i] >> 32) != (hitKey[i - 1] >> 32));
+		c += (i == b) || (hitKey.ext_raw(i) != hitKey.ext_raw(i - 1));
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
 	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
 	__syncthreads();
 	if (threadIdx.x == 0) { u64 t = 0; for (int i = 0; i < WG / 64; ++i) t += sh[i]; groupCnt[q] = t; }
 }
 
-__global__ void k_group_fill(const u64* __restrict__ hitOff, const u64* __restrict__ hitKey,
+// group boundaries + what later kernels need of the keys: target id, first / last query position
+template <class KT>
+__global__ void k_group_fill(const u64* __restrict__ hitOff, HitKeyView<KT> hitKey,
 							 const u64* __restrict__ groupOff, u64* __restrict__ groupStart,
-							 u32* __restrict__ groupQuery)
+							 u32* __restrict__ groupQuery, u32* __restrict__ groupExt,
+							 u32* __restrict__ groupFirstCur, u32* __restrict__ groupLastCur)
 {
 	__shared__ u32 sh[WG / 64 + 1];
 	const u32 q = blockIdx.x;
@@ -468,12 +463,19 @@ __global__ void k_group_fill(const u64* __restrict__ hitOff, const u64* __restri
 	for (u64 i0 = b; i0 < e; i0 += WG)
 	{
 		const u64 i = i0 + threadIdx.x;
-		const bool head = i < e && ((i == b) || ((hitKey[i] >> 32) != (hitKey[i - 1] >> 32)));
+		const bool head = i < e && ((i == b) || (hitKey.ext_raw(i) != hitKey.ext_raw(i - 1)));
 		u32 tot;
 		const u32 pos = block_exscan(head ? 1u : 0u, sh, &tot);
-		if (head) { groupStart[gbase + pos] = i; groupQuery[gbase + pos] = q; }
+		if (head)
+		{
+			const u64 g = gbase + pos;
+			groupStart[g] = i; groupQuery[g] = q;
+			groupExt[g] = hitKey.ext(i); groupFirstCur[g] = hitKey.cur(i);
+			if (i > b) groupLastCur[g - 1] = hitKey.cur(i - 1);	// closes the previous group of this query
+		}
 		gbase += tot;
 	}
+	if (threadIdx.x == 0 && e > b) groupLastCur[gbase - 1] = hitKey.cur(e - 1);
 }
 
 __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
@@ -503,7 +505,7 @@ __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __rest
 
 // primaries of every group -> dense PrimRec array in (query, group, selection) order
 __global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __restrict__ primCount,
-							  const u64* __restrict__ groupStart, const u64* __restrict__ hitKey,
+							  const u64* __restrict__ groupStart, const u32* __restrict__ groupExt,
 							  const u32* __restrict__ gCur, const u32* __restrict__ gExt, const int4* __restrict__ cand,
 							  const i32* __restrict__ len, u32 firstId, int k,
 							  const u64* __restrict__ filtOff, const i32* __restrict__ filtPos,
@@ -525,7 +527,7 @@ __global__ void k_prim_gather(const u64* __restrict__ groupOff, const u32* __res
 		if (cnt)
 		{
 			const u64 g0 = groupStart[g];
-			const u32 extId = (u32)(hitKey[g0] >> 32);
+			const u32 extId = groupExt[g];
 			const i32 extLen = len[(extId - firstId) >> 1];
 			for (u32 a = 0; a < cnt; ++a)
 			{
@@ -717,7 +719,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
 	if (nHits > hitBudget && nq > 1) return false;
 	res->nHits = nHits;
-	c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
+	c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
 	// 32-bit sort keys when (record index, query position) fit together
 	int curBits = 1, recBits = 1;
 	while ((1LL << curBits) < (long long)(c->hasQ ? c->qMaxLen : c->maxLen)) ++curBits;
@@ -730,32 +732,33 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u32>(c, c->dHitOff.p, nq, c->dHitKey32.p, c->dHitVal.p, nHits);
-		if (nHits)
-		{
-			ScopedK t(c->timer, "k_expand_keys");
-			hipLaunchKernelGGL(k_expand_keys, (unsigned)((nHits + WG - 1) / WG), WG, 0, s, c->dHitKey32.p, nHits, curBits,
-							   c->firstId, c->dHitKey.p);
-		}
 	}
 	else
 	{
+		c->dHitKey.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits, curBits);
 	}
+	const HitKeyView<u32> hk32{c->dHitKey32.p, curBits, c->firstId};
+	const HitKeyView<u64> hk64{c->dHitKey.p, curBits, c->firstId};
 	{ ScopedK t(c->timer, "k_group_count");
-	  hipLaunchKernelGGL(k_group_count, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupCnt.p); }
+	  if (key32) hipLaunchKernelGGL(k_group_count<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupCnt.p);
+	  else hipLaunchKernelGGL(k_group_count<u64>, nq, WG, 0, s, c->dHitOff.p, hk64, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
 	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
 	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "too many target groups in one chunk"};
 	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
+	c->dGroupExt.reserve(nGroups + 1); c->dGroupFirstCur.reserve(nGroups + 1); c->dGroupLastCur.reserve(nGroups + 1);
 	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
 	{ ScopedK t(c->timer, "k_group_fill");
-	  hipLaunchKernelGGL(k_group_fill, nq, WG, 0, s, c->dHitOff.p, c->dHitKey.p, c->dGroupOff.p, c->dGroupStart.p,
-						 c->dGroupQuery.p); }
-	fgChainStage(c, p, forceLocal, nGroups, nHits);
+	  if (key32) hipLaunchKernelGGL(k_group_fill<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupOff.p, c->dGroupStart.p,
+									c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p);
+	  else hipLaunchKernelGGL(k_group_fill<u64>, nq, WG, 0, s, c->dHitOff.p, hk64, c->dGroupOff.p, c->dGroupStart.p,
+							  c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p); }
+	fgChainStage(c, p, forceLocal, nGroups, nHits, key32, curBits);
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
 						 c->dDpGroups.p, c->dDpElems.p); }
@@ -767,7 +770,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	if (keepAln) { c->dPrimNode.reserve(nPrim + 1); c->dPrimBase.reserve(nPrim + 1); c->dMatchSize.reserve(nPrim + 1);
 				   c->dMatchOff.reserve(nPrim + 2); c->dMatchCnt.reserve(nPrim + 1); }
 	{ ScopedK t(c->timer, "k_prim_gather");
-	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dGroupStart.p, c->dHitKey.p,
+	  hipLaunchKernelGGL(k_prim_gather, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dGroupStart.p, c->dGroupExt.p,
 						 c->dCur.p, c->dExt.p, c->dCand.p, c->dLen.p, c->firstId, k, c->dFiltOff.p, c->dFiltPos.p,
 						 c->dPrimOff.p, (PrimRec*)c->dPrimOut.p, keepAln ? c->dPrimNode.p : (u64*)nullptr,
 						 keepAln ? c->dPrimBase.p : (u64*)nullptr, keepAln ? c->dMatchSize.p : (u64*)nullptr); }
