@@ -18,6 +18,9 @@ def run(seed=0, n_cases=30, verbose=True):
       cfg = config.preset(preset)
       k = int(rng.choice([15, 17, 17, 17, 21, 31])) if cfg["use_minimizers"] else int(rng.choice([13, 15, 17, 17]))
       glen = int(rng.integers(15_000, 60_000))
+      if kind.startswith("hifi"):
+          glen = max(glen, 45_000)   # 15 kb reads on a genome of their own size: every read overlaps every read over its
+                                     # whole length, densely -- minutes of DP for the oracle and the GPU alike, no new coverage
       cov = int(rng.integers(8, 30))
       rs = synth.simulate(seed=int(rng.integers(1, 1 << 30)), genome_len=glen, coverage=cov, kind=kind,
                           n_homopolymers=int(rng.integers(0, 60)), n_tandems=int(rng.integers(0, 60)),
@@ -45,19 +48,24 @@ def run(seed=0, n_cases=30, verbose=True):
       cfg2 = dict(cfg); cfg2["maximum_jump"] = float(rng.choice([300, 1500, 1500, 5000])); cfg2["hpc_scoring_on"] = float(rng.integers(0, 2))
       maxdiv = float(np.float32(rng.choice([1.0, 0.3, 0.05])))
       mo = int(rng.choice([0, 0, 3, 25])); fl = bool(rng.integers(0, 2))
+      keep = bool(rng.integers(0, 2)); part = bool(rng.integers(0, 3) == 0)
+      if part: mo = 0      # the marks exist only with maxOverlaps = 0
       qsel = rng.choice(["fwd", "rc", "all", "some"])
       allq = first + np.arange(0, 2 * rs.n)
       q = {"fwd": allq[::2], "rc": allq[1::2], "all": allq, "some": rng.choice(allq, size=max(1, rs.n // 2), replace=True)}[qsel].astype(np.uint32)
-      det = gpu.OverlapDetector(ctx, vi, int(cfg2["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], False, dk["only_max_ext"],
-                                maxdiv, dk["nucl_alignment"], False, bool(cfg2["hpc_scoring_on"]))
+      det = gpu.OverlapDetector(ctx, vi, int(cfg2["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], keep, dk["only_max_ext"],
+                                maxdiv, dk["nucl_alignment"], part, bool(cfg2["hpc_scoring_on"]))
       gres = det.getSeqOverlapsBatch(q, forceLocal=fl, maxOverlaps=mo)
-      ores = o.overlaps(O.detector_params(cfg2, max_divergence=maxdiv, **dk), q, max_overlaps=mo, force_local=fl)
+      ores = o.overlaps(O.detector_params(cfg2, max_divergence=maxdiv, keep_alignment=keep, partition_bad_mappings=part, **dk), q,
+                        max_overlaps=mo, force_local=fl)
       same = (gres.lines() == ores.lines() and np.array_equal(gres.query_off, ores.query_off) and
               np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32)) and
-              np.array_equal(gres.recs["edit_distance"], ores.recs["edit_distance"]))
+              np.array_equal(gres.recs["edit_distance"], ores.recs["edit_distance"]) and
+              (not keep or (np.array_equal(gres.match_off, ores.match_off) and np.array_equal(gres.matches, ores.matches))) and
+              (not part or np.array_equal(gres.needs_trim, ores.needs_trim)))
       tag = "ok " if (same and same_idx) else "BAD"
       if not (same and same_idx): bad += 1
-      if verbose: print(f"{tag} case {case}: {kind}/{preset} k={k} reads={rs.n} {dk} jump={int(cfg2['maximum_jump'])} maxdiv={maxdiv} mo={mo} fl={fl} q={qsel} "
+      if verbose: print(f"{tag} case {case}: {kind}/{preset} k={k} reads={rs.n} {dk} jump={int(cfg2['maximum_jump'])} maxdiv={maxdiv} mo={mo} fl={fl} keep={keep} part={part} q={qsel} "
             f"recs={len(gres.recs)} index_same={same_idx}", flush=True)
   print(f"{n_cases} cases, {bad} mismatching, {time.time()-t0:.0f} s")
   return bad
