@@ -317,6 +317,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	// a tile boundary the tile's results are the windows read in reverse lane order.
 	i32 rs = 0, rb = -1;
 	i32 wc = tc, we = te, ws = 0, wb = -1;	// window for i = 1: only lane 0 (element 0: score 0, no predecessor) is meaningful
+	i32 prevC = __builtin_amdgcn_readlane(tc, 0), prevE = __builtin_amdgcn_readlane(te, 0), prevS = 0;
 	for (i32 i = 1; i < n; ++i)
 	{
 		if ((i & 63) == 0)
@@ -337,11 +338,11 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 			// scalar fast path: the predecessor i-1 lies on the same diagonal less than k ahead.
 			// It is the first candidate of the scan, improves on 0 (its score is >= 0) and
 			// triggers the reference's early exit at once (overlap.cpp:301-307).
-			const i32 c0 = __builtin_amdgcn_readlane(wc, 0), e0 = __builtin_amdgcn_readlane(we, 0);
-			const i32 dc0 = cn - c0;
-			if (dc0 == en - e0 && dc0 > 0 && dc0 < k && dc0 < maxJump)
+			// (element i-1's position and score are still in scalar registers from the last step)
+			const i32 dc0 = cn - prevC;
+			if (dc0 == en - prevE && dc0 > 0 && dc0 < k && dc0 < maxJump)
 			{
-				maxScore = __builtin_amdgcn_readlane(ws, 0) + dc0;
+				maxScore = prevS + dc0;
 				maxId = i - 1;
 				done = true;
 			}
@@ -399,6 +400,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 		const i32 sNew = max(maxScore, k);
 		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
 		wb = wave_shr1(wb, maxScore > k ? maxId : -1);
+		prevC = cn; prevE = en; prevS = sNew;
 	}
 	{
 		// last (partial) tile: element tb + L sits on lane n-1-tb-L of the windows

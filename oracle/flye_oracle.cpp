@@ -706,6 +706,17 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 				if (!extSorted && curNext - curPrev > P.max_jump) break;
 			}
 			counters[4] += scanned; counters[5] += scanned > 16; counters[6] += scanned > 64;
+			if (getenv("FO_STATS3"))
+			{
+				static std::atomic<unsigned long long> L[12];	// elements by scan length 1..10, >10; [11] = count
+				L[scanned <= 10 ? scanned - 1 : 10] += 1;
+				if (((L[11] += 1) & 0x3FFFFF) == 0)
+				{
+					fprintf(stderr, "scan length share:");
+					for (int b = 0; b < 11; ++b) fprintf(stderr, " %.3f", (double)L[b] / L[11]);
+					fprintf(stderr, "\n");
+				}
+			}
 			if (getenv("FO_STATS2"))
 			{
 				static std::atomic<unsigned long long> H[8];	// candidate steps at depth <=8,<=16,<=32,<=64,<=128,<=256,more
