@@ -142,6 +142,13 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 #ifndef FIN_CAP_S
 #define FIN_CAP_S 256
 #endif		// <= : LDS, 4 groups per block; larger groups run on global scratch.
+#ifndef FIN_WAVES_S
+#define FIN_WAVES_S 1	// waves (= groups) per block of the <= 256-hit class / of the global-scratch class: one,
+					// so that a block's slot frees when ITS group is done (4 -> 1: 4.97 -> 4.46 and 5.83 -> 5.37 ms)
+#endif
+#ifndef FIN_WAVES_G
+#define FIN_WAVES_G 1
+#endif
 #ifndef FIN_BT_CAP
 #define FIN_BT_CAP 1024	// global-scratch groups up to this size walk their back pointers in LDS
 #endif
@@ -166,7 +173,9 @@ __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __re
 
 // ---- prep --------------------------------------------------------------------------------
 #define PREP_CAP 512
-#define PREP_WAVES 4
+#ifndef PREP_WAVES
+#define PREP_WAVES 1
+#endif
 template <class KT>
 __global__ void __launch_bounds__(PREP_WAVES * 64)
 k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
@@ -276,8 +285,13 @@ __device__ __forceinline__ i32 wave_incl_max(i32 v)
 // the exit conditions cuts the scan.  The group's columns arrive 64 elements at a time in
 // registers, the results leave the same way; only look-backs deeper than 64 (about 1.6 %
 // of the elements on PacBio-raw data) read memory.
-#define DP_WAVES 4
+#ifndef DP_WAVES
+#define DP_WAVES 1	// one group per block: a block's slot frees as soon as ITS group is done (1 / 2 / 4 / 8 waves
+					// per block measured: 12.3 / 13.4 / 13.8 / 14.1 ms)
+#endif
+#ifndef DP_RING
 #define DP_RING 256
+#endif
 __global__ void __launch_bounds__(DP_WAVES * 64)
 k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
@@ -658,12 +672,14 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	if (hc[1])
 	{
 		ScopedK t(c->timer, "k_chain_finish<global>");
-		hipLaunchKernelGGL((k_chain_finish<0, 4, FIN_BT_CAP>), (hc[1] + 3) / 4, 256, 0, s, FIN_ARGS(1));
+		hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc[1] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, s,
+						   FIN_ARGS(1));
 	}
 	if (hc[0])
 	{
 		ScopedK t(c->timer, "k_chain_finish<lds256>");
-		hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, 4>), (hc[0] + 3) / 4, 256, FIN_CAP_S * 20 * 4, s, FIN_ARGS(0));
+		hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, FIN_WAVES_S>), (hc[0] + FIN_WAVES_S - 1) / FIN_WAVES_S, FIN_WAVES_S * 64,
+						   FIN_CAP_S * 20 * FIN_WAVES_S, s, FIN_ARGS(0));
 	}
 #undef FIN_ARGS
 }

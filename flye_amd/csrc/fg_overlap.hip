@@ -232,7 +232,10 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 #define SORT_CAP 512
 #endif
 #ifndef SORT_LDS_WAVES
-#define SORT_LDS_WAVES 4
+#define SORT_LDS_WAVES 1	// pieces per block: one (4 -> 1: 8.86 -> 7.89 ms; uneven pieces hold a shared block)
+#endif
+#ifndef SORT_LEVEL_WAVES
+#define SORT_LEVEL_WAVES 1	// tasks per block of k_sort_level
 #endif
 struct SortTask { u64 start; u32 n; u32 depth; };
 
@@ -323,7 +326,7 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT*
 							 SortTask* __restrict__ children, u32 streamMax)
 {
 	const int lane = threadIdx.x & 63;
-	const u32 ti = blockIdx.x * (WG / 64) + (threadIdx.x >> 6);
+	const u32 ti = blockIdx.x * SORT_LEVEL_WAVES + (threadIdx.x >> 6);
 	if (ti >= nTasks) return;
 	SortTask t = tasks[ti];
 	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
@@ -645,7 +648,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 			hipLaunchKernelGGL(k_sort_wide<KT>, nWide, SORT_WIDE_WAVES * 64, 0, s, wideA, nWide, dK, dV, c->dTmp32.p, nHits,
 							   kids + 2 * (size_t)nBig);
 		if (nBig)
-			hipLaunchKernelGGL(k_sort_level<KT>, (nBig + WG / 64 - 1) / (WG / 64), WG, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits,
+			hipLaunchKernelGGL(k_sort_level<KT>, (nBig + SORT_LEVEL_WAVES - 1) / SORT_LEVEL_WAVES, SORT_LEVEL_WAVES * 64, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits,
 							   kids, streamMax);
 		const u32 nKids = 2 * (nBig + nWide);
 		hipLaunchKernelGGL(k_sort_route, (nKids + WG - 1) / WG, WG, 0, s, kids, nKids, bigB, wideB, wideMin, smallT, smallCap,
