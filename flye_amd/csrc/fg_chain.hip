@@ -172,7 +172,9 @@ __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __re
 }
 
 // ---- prep --------------------------------------------------------------------------------
-#define PREP_CAP 512
+#ifndef PREP_CAP
+#define PREP_CAP 320	// 128 / 192 / 256 / 320 / 512 measured: 5.2 / 4.95 / 4.8 / 4.7 / 5.15 ms
+#endif
 #ifndef PREP_WAVES
 #define PREP_WAVES 1
 #endif

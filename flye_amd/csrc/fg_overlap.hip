@@ -229,7 +229,7 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 // with 10^5..10^6 hits thus spreads over more waves at every level instead of serialising
 // ~10 levels on one wave.
 #ifndef SORT_CAP
-#define SORT_CAP 512
+#define SORT_CAP 448	// levels + LDS kernel at 256 / 320 / 384 / 448 / 512 / 1024: 20.5 / 19.1 / 19.5 / 18.8 / 20.1 / 21.4 ms
 #endif
 #ifndef SORT_LDS_WAVES
 #define SORT_LDS_WAVES 1	// pieces per block: one (4 -> 1: 8.86 -> 7.89 ms; uneven pieces hold a shared block)
