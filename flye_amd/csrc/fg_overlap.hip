@@ -290,7 +290,9 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 }
 
 // a workgroup of SORT_WIDE_WAVES waves per task: one partition of a huge piece
+#ifndef SORT_WIDE_WAVES
 #define SORT_WIDE_WAVES 8
+#endif
 template <class KT>
 __global__ void __launch_bounds__(SORT_WIDE_WAVES * 64)
 k_sort_wide(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hitKey,
