@@ -465,19 +465,37 @@ __global__ void k_group_fill(const u64* __restrict__ hitOff, HitKeyView<KT> hitK
 	const u32 q = blockIdx.x;
 	const u64 b = hitOff[q], e = hitOff[q + 1];
 	u64 gbase = groupOff[q];
-	for (u64 i0 = b; i0 < e; i0 += WG)
+	// GF consecutive hits per thread and step: one block scan (two barriers) per GF * 256 hits
+	constexpr int GF = 4;
+	for (u64 i0 = b; i0 < e; i0 += (u64)WG * GF)
 	{
-		const u64 i = i0 + threadIdx.x;
-		const bool head = i < e && ((i == b) || (hitKey.ext_raw(i) != hitKey.ext_raw(i - 1)));
-		u32 tot;
-		const u32 pos = block_exscan(head ? 1u : 0u, sh, &tot);
-		if (head)
+		const u64 first = i0 + (u64)threadIdx.x * GF;
+		u32 raw[GF + 1];
+		raw[0] = (first > b && first - 1 < e) ? hitKey.ext_raw(first - 1) : 0u;
+#pragma unroll
+		for (int t = 0; t < GF; ++t) raw[t + 1] = first + t < e ? hitKey.ext_raw(first + t) : 0u;
+		u32 nHead = 0;
+		bool head[GF];
+#pragma unroll
+		for (int t = 0; t < GF; ++t)
 		{
-			const u64 g = gbase + pos;
-			groupStart[g] = i; groupQuery[g] = q;
-			groupExt[g] = hitKey.ext(i); groupFirstCur[g] = hitKey.cur(i);
-			if (i > b) groupLastCur[g - 1] = hitKey.cur(i - 1);	// closes the previous group of this query
+			const u64 i = first + t;
+			head[t] = i < e && ((i == b) || (raw[t + 1] != raw[t]));
+			nHead += head[t];
 		}
+		u32 tot;
+		u32 pos = block_exscan(nHead, sh, &tot);
+#pragma unroll
+		for (int t = 0; t < GF; ++t)
+			if (head[t])
+			{
+				const u64 i = first + t;
+				const u64 g = gbase + pos;
+				groupStart[g] = i; groupQuery[g] = q;
+				groupExt[g] = hitKey.ext(i); groupFirstCur[g] = hitKey.cur(i);
+				if (i > b) groupLastCur[g - 1] = hitKey.cur(i - 1);	// closes the previous group of this query
+				++pos;
+			}
 		gbase += tot;
 	}
 	if (threadIdx.x == 0 && e > b) groupLastCur[gbase - 1] = hitKey.cur(e - 1);
