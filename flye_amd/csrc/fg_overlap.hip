@@ -162,7 +162,7 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 	__shared__ u32 sh[WG / 64 + 1];
 	__shared__ u32 sStart[WG + 1];
 	__shared__ u64 sOff[WG];
-	__shared__ u32 sSelf[WG];	// index of the trivial self hit inside the list, or 0xFFFFFFFF
+	__shared__ u32 sSelf[WG];	// 1: the list holds this position's own (trivial) entry
 	const u32 q = blockIdx.x;
 	const u32 rec = query[q];
 	const i32 L = qLen[rec >> 1];
@@ -179,23 +179,17 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 		if (rep) cnt = 0;
 		const bool flip = v & FLAG_FLIP;
 		const u64 off = (v >> FG_CNT_BITS) & OFF_MASK;
-		u32 selfIdx = 0xFFFFFFFFu;
-		if (cnt && (v & FLAG_SELF))
-		{
-			// the list is ascending: find this position's own entry (it exists)
-			const u64 own = ((u64)(rec ^ (flip ? 1u : 0u)) << 32) | (u32)(flip ? L - p - k : p);
-			u32 lo = 0, hi = cnt;
-			while (lo < hi) { const u32 m = (lo + hi) >> 1; if (entries[off + m] < own) lo = m + 1; else hi = m; }
-			selfIdx = lo;
-		}
-		const u32 eff = cnt - (selfIdx != 0xFFFFFFFFu ? 1u : 0u);
+		// the trivial self hit is dropped in the output walk below (no search here: a per-position
+		// binary search of the list put log2(cnt) dependent loads on every step of the block)
+		const bool hasSelf = cnt && (v & FLAG_SELF);
+		const u32 eff = cnt - (hasSelf ? 1u : 0u);
 		u32 tot, ftot;
 		const u32 start = block_exscan(eff, sh, &tot);
 		const u32 fstart = block_exscan(rep ? 1u : 0u, sh, &ftot);
 		if (rep) filtPos[fbase + fstart] = p;
 		sStart[threadIdx.x] = start;
 		sOff[threadIdx.x] = off | (flip ? FLAG_FLIP : 0ULL);
-		sSelf[threadIdx.x] = selfIdx;
+		sSelf[threadIdx.x] = hasSelf ? 1u : 0u;
 		if (threadIdx.x == 0) sStart[WG] = tot;
 		__syncthreads();
 		for (u32 o = threadIdx.x; o < tot; o += WG)
@@ -204,10 +198,18 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 			u32 lo = 0, hi = WG;
 			while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (sStart[m] <= o) lo = m; else hi = m; }
 			const u32 t = lo;
-			u32 j = o - sStart[t];
-			if (j >= sSelf[t]) ++j;	// no trivial matches (overlap.cpp:188-190)
+			const u32 j = o - sStart[t];
 			const u64 so = sOff[t];
-			const u64 e = entries[(so & OFF_MASK) + j];
+			u64 e = entries[(so & OFF_MASK) + j];
+			if (sSelf[t])
+			{
+				// no trivial matches (overlap.cpp:188-190): the list is ascending and holds this
+				// position's own entry exactly once; output j is entry j before it, entry j + 1 after
+				const i32 pq = p0 + (i32)t;
+				const bool fl = so & FLAG_FLIP;
+				const u64 own = ((u64)(rec ^ (fl ? 1u : 0u)) << 32) | (u32)(fl ? L - pq - k : pq);
+				if (e >= own) e = entries[(so & OFF_MASK) + j + 1];
+			}
 			u32 srec = (u32)(e >> 32);
 			i32 spos = (i32)(u32)e;
 			if (so & FLAG_FLIP) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
