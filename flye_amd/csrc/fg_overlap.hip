@@ -115,6 +115,11 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 		fg_kmer_pair(w, qf, k, a, b);
 		const u64 fw = rc ? b : a, rv = rc ? a : b;
 		const bool flip = rv < fw;
+		// the "this position owns an entry" bit is fetched alongside the probe (its address only
+		// depends on the position), not behind it
+		// forward position nk (= L-k) is never a forward k-mer position (kmer.h:193-198)
+		const u64 bit = kbase + (u64)qf;
+		const u32 selfWord = (indexedBits && qf < nk) ? indexedBits[bit >> 5] : 0u;
 		u64 v = fg_probe(table, tmask, flip ? rv : fw);
 		if (v != 0)
 		{
@@ -122,9 +127,7 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 			if (cnt == FG_CNT_REPETITIVE) ++filt;
 			else
 			{
-				// forward position nk (= L-k) is never a forward k-mer position (kmer.h:193-198)
-				const u64 bit = kbase + (u64)qf;
-				const u32 self = (indexedBits && qf < nk) ? (indexedBits[bit >> 5] >> (bit & 31)) & 1u : 0u;
+				const u32 self = (selfWord >> (bit & 31)) & 1u;
 				hits += cnt - self;
 				if (self) v |= FLAG_SELF;
 				if (flip) v |= FLAG_FLIP;
