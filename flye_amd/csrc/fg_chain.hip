@@ -185,7 +185,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 			 const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
 			 HitKeyView<KT> hitKey, const u32* __restrict__ groupExt, const u32* __restrict__ hitVal,
 			 u32* __restrict__ gCur, u32* __restrict__ gExt, u32* __restrict__ gAux /* 4 u32 per hit */,
-			 u32* __restrict__ dpSize)
+			 u32* __restrict__ dpSize, uint8_t* __restrict__ groupExtSorted)
 {
 	__shared__ u32 sExt[PREP_WAVES][PREP_CAP];
 	__shared__ u32 sCur[PREP_WAVES][PREP_CAP];
@@ -237,7 +237,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		if (min(minCur, minExt) > P.maxOverhang) return;
 		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
 	}
-	if (lane == 0) dpSize[g] = (u32)n;
+	if (lane == 0) { dpSize[g] = (u32)n; groupExtSorted[g] = extLen > curLen ? 1 : 0; }
 
 	u32* oc = gCur + g0;
 	u32* oe = gExt + g0;
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(DP_WAVES * 64)
 k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 		   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-		   const u32* __restrict__ groupExt,
+		   const uint8_t* __restrict__ groupExtSorted,
 		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
 		   i32* __restrict__ gScore, i32* __restrict__ gBack)
 {
@@ -309,9 +309,7 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	const u64 g0 = fg_uni(groupStart[g]);
 	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
-	const u32 qrec = fg_uni(query[groupQuery[g]]);
-	const u32 extRec = fg_uni(groupExt[g]) - P.firstId;
-	const bool extSorted = fg_uni(len[extRec >> 1]) > fg_uni(qLen[qrec >> 1]);
+	const bool extSorted = fg_uni((u32)groupExtSorted[g]) != 0;	// decided by k_group_prep
 	const u32* cur = gCur + g0;
 	const u32* ext = gExt + g0;
 	i32* score = gScore + g0;
@@ -627,6 +625,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	while ((float)minSize < cp.minUnique) ++minSize;
 	if (minSize == 0) minSize = 1;
 	c->dListSmall.reserve(nGroups + 1); c->dListBig.reserve(nGroups + 1); c->dListDp.reserve(nGroups + 1);
+	c->dGroupExtSorted.reserve(nGroups + 1);
 	c->dListCnt.reserve(4);
 	c->dCur.reserve(nHits + 16); c->dExt.reserve(nHits + 16);
 	c->dScore.reserve(nHits + 16); c->dBack.reserve(nHits + 16);
@@ -645,12 +644,12 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		hipLaunchKernelGGL(k_group_prep<u32>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
 						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
 						   HitKeyView<u32>{c->dHitKey32.p, curBits, c->firstId}, c->dGroupExt.p,
-						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p);
+						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p);
 	  else
 		hipLaunchKernelGGL(k_group_prep<u64>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
 						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
 						   HitKeyView<u64>{c->dHitKey.p, curBits, c->firstId}, c->dGroupExt.p,
-						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p); }
+						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p); }
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_dp_list");
 	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListSmall.p, c->dListDp.p,
@@ -665,7 +664,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 			{
 				ScopedK t(c->timer, "k_chain_dp");
 				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
-								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dGroupExt.p,
+								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dGroupExtSorted.p,
 								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
 			}
 	}

@@ -190,6 +190,7 @@ struct fg_ctx {
 	// per group: its target id and the query position of its first and last hit (what the
 	// chaining kernels and the span prefilter need of the sorted keys)
 	DevBuf<u32> dGroupExt, dGroupFirstCur, dGroupLastCur;
+	DevBuf<uint8_t> dGroupExtSorted;	// written by k_group_prep: the DP runs in extPos order (overlap.cpp:268-275)
 	DevBuf<u32> dTmp32;
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
 	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
