@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(PREP_WAVES * 64)
 k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
 			 const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
 			 const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-			 HitKeyView<KT> hitKey, const u32* __restrict__ groupExt, const u32* __restrict__ hitVal,
+			 HitKeyView<KT> hitKey, const u32* __restrict__ groupExt,
 			 u32* __restrict__ gCur, u32* __restrict__ gExt, u32* __restrict__ gAux /* 4 u32 per hit */,
 			 u32* __restrict__ dpSize, uint8_t* __restrict__ groupExtSorted)
 {
@@ -200,7 +200,6 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	const u64 g0 = fg_uni(groupStart[g]);
 	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
 	const i32 n = (i32)(gend - g0);
-	const u32* V = hitVal + g0;
 
 	// the lookups that only the survivors need are issued first, so that their round trips overlap
 	// the pass over the hits instead of following it
@@ -220,7 +219,7 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 		const u32 c = hitKey.cur(g0 + i);
 		const u32 pc = i ? hitKey.cur(g0 + i - 1) : 0u;
 		uniq += (c != pc);
-		const i32 e = (i32)V[i];
+		const i32 e = (i32)hitKey.val(g0 + i);
 		minExt = min(minExt, e); maxExt = max(maxExt, e);
 		if (inLds) { sCur[wv][i] = c; sExt[wv][i] = (u32)e; }
 	}
@@ -251,11 +250,11 @@ k_group_prep(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups
 	}
 	else if (!extSorted)
 	{
-		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = V[i]; }
+		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = hitKey.val(g0 + i); }
 	}
 	else
 	{
-		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = V[i]; }
+		for (i32 i = lane; i < n; i += 64) { oc[i] = hitKey.cur(g0 + i); oe[i] = hitKey.val(g0 + i); }
 		wsort::wave_mem_fence();
 		u32* aux = gAux + 4 * g0;
 		wsort::wave_sort<u32, u32>(oe, oc, n, aux, aux + n, stack[wv], small[wv]);
@@ -602,7 +601,7 @@ u32 fetchU32(fg_ctx* c, const u32* dptr)
 
 // All target groups of the batch -> dPrimFlag[g] = number of primaries (their (first, last,
 // chainLength, score) tuples at the head of the group's dCand region), dDpSize[g]
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, bool key32,
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits)
 {
 	hipStream_t s = c->stream;
@@ -640,16 +639,20 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	const u32 nPrep = fetchU32(c, c->dListCnt.p);
 	if (!nPrep) return;
 	{ ScopedK t(c->timer, "k_group_prep");
-	  if (key32)
-		hipLaunchKernelGGL(k_group_prep<u32>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
-						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
-						   HitKeyView<u32>{c->dHitKey32.p, curBits, c->firstId}, c->dGroupExt.p,
-						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p);
+#define PREP_ARGS(view) cp, c->dListSmall.p, nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
+		view, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p
+	  const unsigned gridP = (nPrep + PREP_WAVES - 1) / PREP_WAVES;
+	  if (keyMode == 0)
+		hipLaunchKernelGGL(k_group_prep<u32>, gridP, PREP_WAVES * 64, 0, s,
+						   PREP_ARGS((HitKeyView<u32>{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId})));
+	  else if (keyMode == 1)
+		hipLaunchKernelGGL(k_group_prep<PK>, gridP, PREP_WAVES * 64, 0, s,
+						   PREP_ARGS((HitKeyView<PK>{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId})));
 	  else
-		hipLaunchKernelGGL(k_group_prep<u64>, (nPrep + PREP_WAVES - 1) / PREP_WAVES, PREP_WAVES * 64, 0, s, cp, c->dListSmall.p,
-						   nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen,
-						   HitKeyView<u64>{c->dHitKey.p, curBits, c->firstId}, c->dGroupExt.p,
-						   c->dHitVal.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p); }
+		hipLaunchKernelGGL(k_group_prep<u64>, gridP, PREP_WAVES * 64, 0, s,
+						   PREP_ARGS((HitKeyView<u64>{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId})));
+#undef PREP_ARGS
+	}
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_dp_list");
 	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListSmall.p, c->dListDp.p,

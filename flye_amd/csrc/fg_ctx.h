@@ -223,20 +223,57 @@ __device__ __forceinline__ u64 fg_uni(u64 v)
 		   (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
 }
 
+// One 64-bit sort RECORD for workloads whose (record, query position) pairs do not fit 32 bits:
+// (record << (curBits + 24)) | (curPos << 24) | extPos.  Ordered (and tested for >=, <=) on the upper
+// bits only -- the (extId, curPos) comparator of overlap.cpp:201-204; the target position rides in the
+// low 24 bits, so a hit stays 8 bytes in the sort levels instead of 8 + 4.  == / != look at all bits.
+#define FG_PK_VALBITS 24
+struct PK {
+	u64 v;
+	PK() = default;
+	__host__ __device__ PK(int x) : v((u64)(unsigned)x) {}
+	__host__ __device__ explicit PK(u64 x) : v(x) {}
+};
+__device__ __forceinline__ bool operator<(const PK& a, const PK& b) { return (a.v >> FG_PK_VALBITS) < (b.v >> FG_PK_VALBITS); }
+__device__ __forceinline__ bool operator>(const PK& a, const PK& b) { return (a.v >> FG_PK_VALBITS) > (b.v >> FG_PK_VALBITS); }
+__device__ __forceinline__ bool operator<=(const PK& a, const PK& b) { return (a.v >> FG_PK_VALBITS) <= (b.v >> FG_PK_VALBITS); }
+__device__ __forceinline__ bool operator>=(const PK& a, const PK& b) { return (a.v >> FG_PK_VALBITS) >= (b.v >> FG_PK_VALBITS); }
+__device__ __forceinline__ bool operator==(const PK& a, const PK& b) { return a.v == b.v; }
+__device__ __forceinline__ bool operator!=(const PK& a, const PK& b) { return a.v != b.v; }
+
+// "no value array": reads give 0, writes vanish (the value travels inside a PK record)
+struct NoVal {
+	struct Ref {
+		__device__ __forceinline__ operator u32() const { return 0u; }
+		__device__ __forceinline__ const Ref& operator=(u32) const { return *this; }
+	};
+	__device__ __forceinline__ Ref operator[](long long) const { return Ref{}; }
+	__device__ __forceinline__ NoVal operator+(long long) const { return NoVal{}; }
+};
+
 // the sorted hit keys, typed at compile time: u64 = (extId << 32 | curPos),
-// u32 = ((extId - firstId) << curBits | curPos)
+// u32 = ((extId - firstId) << curBits | curPos), PK = the packed record above
 template <class KT> struct HitKeyView;
 template <> struct HitKeyView<u64> {
-	const u64* k; int curBits; u32 firstId;
+	const u64* k; const u32* v; int curBits; u32 firstId;
 	__device__ __forceinline__ u32 ext(u64 i) const { return (u32)(k[i] >> 32); }
 	__device__ __forceinline__ u32 ext_raw(u64 i) const { return (u32)(k[i] >> 32); }
 	__device__ __forceinline__ u32 cur(u64 i) const { return (u32)k[i]; }
+	__device__ __forceinline__ u32 val(u64 i) const { return v[i]; }
 };
 template <> struct HitKeyView<u32> {
-	const u32* k; int curBits; u32 firstId;
+	const u32* k; const u32* v; int curBits; u32 firstId;
 	__device__ __forceinline__ u32 ext(u64 i) const { return (k[i] >> curBits) + firstId; }
 	__device__ __forceinline__ u32 ext_raw(u64 i) const { return k[i] >> curBits; }
 	__device__ __forceinline__ u32 cur(u64 i) const { return k[i] & ((1u << curBits) - 1u); }
+	__device__ __forceinline__ u32 val(u64 i) const { return v[i]; }
+};
+template <> struct HitKeyView<PK> {
+	const PK* k; const u32* v; int curBits; u32 firstId;
+	__device__ __forceinline__ u32 ext(u64 i) const { return (u32)(k[i].v >> (FG_PK_VALBITS + curBits)) + firstId; }
+	__device__ __forceinline__ u32 ext_raw(u64 i) const { return (u32)(k[i].v >> (FG_PK_VALBITS + curBits)); }
+	__device__ __forceinline__ u32 cur(u64 i) const { return (u32)(k[i].v >> FG_PK_VALBITS) & ((1u << curBits) - 1u); }
+	__device__ __forceinline__ u32 val(u64 i) const { return (u32)k[i].v & ((1u << FG_PK_VALBITS) - 1u); }
 };
 
 __device__ __forceinline__ u64 fg_mix(u64 x)
@@ -344,7 +381,8 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
-void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, bool key32,
+// keyMode: 0 = 32-bit keys, 1 = packed 64-bit records (PK), 2 = 64-bit keys + values
+void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);

@@ -26,6 +26,7 @@
 #include <chrono>
 #include <functional>
 #include <thread>
+#include <type_traits>
 
 #define WG 256
 #define FLAG_SELF (1ULL << 63)
@@ -216,9 +217,15 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 			u32 srec = (u32)(e >> 32);
 			i32 spos = (i32)(u32)e;
 			if (so & FLAG_FLIP) { spos = len[srec >> 1] - spos - k; srec ^= 1u; }
-			if (sizeof(KT) == 8) hitKey[hbase + o] = (KT)(((u64)(firstId + srec) << 32) | (u32)(p0 + (i32)t));
-			else hitKey[hbase + o] = (KT)((srec << curBits) | (u32)(p0 + (i32)t));
-			hitVal[hbase + o] = (u32)spos;
+			if constexpr (std::is_same<KT, PK>::value)
+				hitKey[hbase + o] = PK(((u64)srec << (curBits + FG_PK_VALBITS)) | ((u64)(u32)(p0 + (i32)t) << FG_PK_VALBITS) |
+									   (u64)(u32)spos);
+			else
+			{
+				if (sizeof(KT) == 8) hitKey[hbase + o] = (KT)(((u64)(firstId + srec) << 32) | (u32)(p0 + (i32)t));
+				else hitKey[hbase + o] = (KT)((srec << curBits) | (u32)(p0 + (i32)t));
+				hitVal[hbase + o] = (u32)spos;
+			}
 		}
 		__syncthreads();
 		hbase += tot;
@@ -243,6 +250,16 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 #define SORT_LEVEL_WAVES 1	// tasks per block of k_sort_level
 #endif
 struct SortTask { u64 start; u32 n; u32 depth; };
+
+// the value array that goes with a key type: a real u32 array, or nothing for packed records
+template <class KT> struct ValPtr {
+	typedef u32* type;
+	static __device__ __forceinline__ type at(u32* v, u64 off) { return v + off; }
+};
+template <> struct ValPtr<PK> {
+	typedef NoVal type;
+	static __device__ __forceinline__ type at(u32*, u64) { return NoVal{}; }
+};
 
 // block-aggregated append (one atomic per list and block).  Lists: big (one wave per task in
 // k_sort_level), wide (> wideMin elements: a whole workgroup per task, k_sort_wide), small
@@ -310,11 +327,11 @@ k_sort_wide(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hit
 	SortTask t = tasks[ti];
 	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
 	KT* K = hitKey + t.start;
-	u32* V = hitVal + t.start;
+	typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
 	SortTask c0{0, 0, 0}, c1{0, 0, 0};
 	if (t.depth == 0)
 	{
-		if (threadIdx.x == 0) { wsort::PtrAcc<KT> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		if (threadIdx.x == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
 	}
 	else
 	{
@@ -338,19 +355,19 @@ __global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT*
 	SortTask t = tasks[ti];
 	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
 	KT* K = hitKey + t.start;
-	u32* V = hitVal + t.start;
+	typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
 	SortTask c0{0, 0, 0}, c1{0, 0, 0};
 	if (t.depth == 0)
 	{
-		if (lane == 0) { wsort::PtrAcc<KT> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		if (lane == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
 	}
 	else
 	{
 		// many medium pieces in flight: the streamed form moves fewer bytes; few huge pieces:
 		// the closed form has no serial chain
 		const int cut = t.n <= streamMax
-			? wsort::partition_stream<KT>(K, V, 0, (int)t.n)
-			: wsort::partition_cf<KT>(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+			? wsort::partition_stream(K, V, 0, (int)t.n)
+			: wsort::partition_cf(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
 		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
 		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
 	}
@@ -390,7 +407,64 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	KT* K = hitKey + t.start;
 	u32* V = hitVal + t.start;
 	const int n = (int)t.n;
-	if (sizeof(KT) == 4)
+	if constexpr (std::is_same<KT, PK>::value)
+	{
+		// packed records: key = v >> 24 ((record, curPos), <= 40 bits), value = the low 24 bits.
+		// Narrowed to 32 bits relative to the piece's minimum key when the piece spans little enough.
+		const u64 vmask = (1ULL << FG_PK_VALBITS) - 1;
+		u64 pk[(SORT_CAP + 63) / 64];
+		u64 mn = ~0ULL, mx = 0;
+#pragma unroll
+		for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
+		{
+			const int i = j * 64 + lane;
+			const u64 rec = i < n ? K[i].v : 0;
+			pk[j] = rec;
+			const u64 key = rec >> FG_PK_VALBITS;
+			if (i < n) { mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
+		}
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			const u64 a = wsort::shflk(mn, lane ^ o), b = wsort::shflk(mx, lane ^ o);
+			mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+		}
+		mn = fg_uni(mn); mx = fg_uni(mx);
+		if (mx - mn <= narrowMax)
+		{
+#pragma unroll
+			for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
+			{
+				const int i = j * 64 + lane;
+				if (i < n) { sK[wv][i] = (u32)((pk[j] >> FG_PK_VALBITS) - mn); sV[wv][i] = (u32)(pk[j] & vmask); }
+			}
+			wsort::wave_mem_fence();
+			wsort::wave_sort<u32, unsigned short>(sK[wv], sV[wv], n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+			for (int i = lane; i < n; i += 64) K[i] = PK((((u64)sK[wv][i] + mn) << FG_PK_VALBITS) | (u64)sV[wv][i]);
+		}
+		else
+		{
+			// a piece spanning more than 2^32 keys (rare): keys widened in place in global memory, the
+			// values parked in the position scratch, position lists in LDS
+			u64* K64 = (u64*)K;
+			u32* vals = posScratch + t.start;
+#pragma unroll
+			for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
+			{
+				const int i = j * 64 + lane;
+				if (i < n) { K64[i] = pk[j] >> FG_PK_VALBITS; vals[i] = (u32)(pk[j] & vmask); }
+			}
+			wsort::wave_mem_fence();
+			wsort::wave_sort<u64, unsigned short>(K64, vals, n, sPL[wv], sPR[wv], stack[wv], small[wv], 0, (int)t.depth);
+			for (int i = lane; i < n; i += 64)
+			{
+				const u64 key = K64[i];
+				const u32 val = vals[i];
+				K[i] = PK((key << FG_PK_VALBITS) | (u64)val);
+			}
+		}
+		return;
+	}
+	else if constexpr (sizeof(KT) == 4)
 	{
 		for (int i = lane; i < n; i += 64) { sK[wv][i] = (u32)K[i]; sV[wv][i] = V[i]; }
 		wsort::wave_mem_fence();
@@ -398,6 +472,8 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 		for (int i = lane; i < n; i += 64) { K[i] = (KT)sK[wv][i]; V[i] = sV[wv][i]; }
 		return;
 	}
+	else
+	{
 	// 64-bit keys (extId << 32 | curPos): a piece of <= 512 hits of one query usually spans few
 	// target records, so (extId << curBits | curPos) minus the piece's minimum fits 32 bits -- an
 	// order-preserving map, hence the same permutation at the 32-bit kernel's cost.  curBits = 0
@@ -441,6 +517,7 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	// a piece that spans more than 2^32 packed keys: sorted where it lies, in global memory
 	wsort::wave_sort<KT, u32>(K, V, n, posScratch + t.start, posScratch + nHits + t.start, stack[wv], small[wv], 0,
 							  (int)t.depth);
+	}
 }
 
 // ---- target groups ---------------------------------------------------------------------
@@ -747,32 +824,48 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
 	if (nHits > hitBudget && nq > 1) return false;
 	res->nHits = nHits;
-	c->dHitVal.reserve(nHits + 1); c->dFiltPos.reserve(nFilt + 1);
+	c->dFiltPos.reserve(nFilt + 1);
 	// 32-bit sort keys when (record index, query position) fit together
 	int curBits = 1, recBits = 1;
 	while ((1LL << curBits) < (long long)(c->hasQ ? c->qMaxLen : c->maxLen)) ++curBits;
 	while ((1ULL << recBits) < 2ULL * c->nReads) ++recBits;
 	const bool key32 = curBits + recBits <= 32 && !getenv("FG_FORCE_KEY64");
-	if (key32)
+	// key mode: 0 = 32-bit keys + values; when (record, curPos) need more than 32 bits: 1 = packed 64-bit
+	// records (PK: record, curPos, extPos in one word, 8 bytes per hit in the sort levels instead of 12;
+	// FG_PACKED_KEYS=0 turns it off), else 2 = 64-bit keys + values
+	const bool canPack = recBits + curBits + FG_PK_VALBITS <= 64 && c->maxLen < (1 << FG_PK_VALBITS);
+	const bool wantPack = !(getenv("FG_PACKED_KEYS") && atoi(getenv("FG_PACKED_KEYS")) == 0);
+	const int keyMode = key32 ? 0 : ((canPack && wantPack) ? 1 : 2);
+	if (keyMode == 0)
 	{
-		c->dHitKey32.reserve(nHits + 1);
+		c->dHitKey32.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u32>(c, c->dHitOff.p, nq, c->dHitKey32.p, c->dHitVal.p, nHits);
 	}
-	else
+	else if (keyMode == 1)
 	{
 		c->dHitKey.reserve(nHits + 1);
+		{ ScopedK t(c->timer, "k_fill");
+		  hipLaunchKernelGGL(k_fill<PK>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
+							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, (PK*)c->dHitKey.p, (u32*)nullptr, c->dFiltPos.p); }
+		sortSegments<PK>(c, c->dHitOff.p, nq, (PK*)c->dHitKey.p, (u32*)nullptr, nHits, curBits);
+	}
+	else
+	{
+		c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits, curBits);
 	}
-	const HitKeyView<u32> hk32{c->dHitKey32.p, curBits, c->firstId};
-	const HitKeyView<u64> hk64{c->dHitKey.p, curBits, c->firstId};
+	const HitKeyView<u32> hk32{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId};
+	const HitKeyView<u64> hk64{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId};
+	const HitKeyView<PK> hkp{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId};
 	{ ScopedK t(c->timer, "k_group_count");
-	  if (key32) hipLaunchKernelGGL(k_group_count<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupCnt.p);
+	  if (keyMode == 0) hipLaunchKernelGGL(k_group_count<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupCnt.p);
+	  else if (keyMode == 1) hipLaunchKernelGGL(k_group_count<PK>, nq, WG, 0, s, c->dHitOff.p, hkp, c->dGroupCnt.p);
 	  else hipLaunchKernelGGL(k_group_count<u64>, nq, WG, 0, s, c->dHitOff.p, hk64, c->dGroupCnt.p); }
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
@@ -782,11 +875,13 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	c->dGroupExt.reserve(nGroups + 1); c->dGroupFirstCur.reserve(nGroups + 1); c->dGroupLastCur.reserve(nGroups + 1);
 	c->dPrimFlag.reserve(nGroups + 1); c->dDpSize.reserve(nGroups + 1);
 	{ ScopedK t(c->timer, "k_group_fill");
-	  if (key32) hipLaunchKernelGGL(k_group_fill<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupOff.p, c->dGroupStart.p,
-									c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p);
+	  if (keyMode == 0) hipLaunchKernelGGL(k_group_fill<u32>, nq, WG, 0, s, c->dHitOff.p, hk32, c->dGroupOff.p, c->dGroupStart.p,
+										   c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p);
+	  else if (keyMode == 1) hipLaunchKernelGGL(k_group_fill<PK>, nq, WG, 0, s, c->dHitOff.p, hkp, c->dGroupOff.p, c->dGroupStart.p,
+												c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p);
 	  else hipLaunchKernelGGL(k_group_fill<u64>, nq, WG, 0, s, c->dHitOff.p, hk64, c->dGroupOff.p, c->dGroupStart.p,
 							  c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p); }
-	fgChainStage(c, p, forceLocal, nGroups, nHits, key32, curBits);
+	fgChainStage(c, p, forceLocal, nGroups, nHits, keyMode, curBits);
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
 						 c->dDpGroups.p, c->dDpElems.p); }

@@ -27,10 +27,10 @@ __device__ int g_ablate = 0;
 template <class KT>
 struct KV { KT k; u32 v; };
 
-template <class KT>
+template <class KT, class VP = u32*>
 struct PtrAcc {
 	typedef KV<KT> T;
-	KT* K; u32* V;
+	KT* K; VP V;
 	__device__ __forceinline__ T load(int i) const { return T{K[i], V[i]}; }
 	__device__ __forceinline__ void store(int i, const T& x) { K[i] = x.k; V[i] = x.v; }
 	__device__ __forceinline__ bool less(const T& a, const T& b) const { return a.k < b.k; }
@@ -56,6 +56,7 @@ __device__ __forceinline__ u64 shflk(u64 v, int src)
 	return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u32 shflk(u32 v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ PK shflk(PK v, int src) { return PK(shflk(v.v, src)); }
 
 // whole-wave rotation by one lane (DPP wave_ror:1 = 0x13C, wave_rol:1 = 0x134)
 template <int CTRL>
@@ -320,8 +321,8 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 // maximum sits in the tile where they cross.  Phase 3 lists only the 2K stops that swap,
 // phase 4 swaps pair k = (l_k, r_k); no iteration of either depends on another.
 // sL / sR: >= (last - first) entries each (lists in front, tile prefixes behind the middle).
-template <class KT>
-__device__ __forceinline__ int partition_cf(KT* K, u32* V, int first, int last, u32* sL, u32* sR)
+template <class KT, class VP = u32*>
+__device__ __forceinline__ int partition_cf(KT* K, VP V, int first, int last, u32* sL, u32* sR)
 {
 	const int lane = threadIdx.x & 63;
 	first = uni(first); last = uni(last);
@@ -495,8 +496,8 @@ __device__ __forceinline__ int partition_cf(KT* K, u32* V, int first, int last, 
 // partition_cf by a whole workgroup of WW waves on one huge segment [0, n): the tiles of phases
 // 1 and 3 and the pairs of phase 4 are dealt to the waves, phase 2 is computed by every wave.
 // shm: >= 2 * WW ints of LDS.  All threads of the block must call.
-template <class KT, int WW>
-__device__ __forceinline__ int partition_cf_block(KT* K, u32* V, int n, u32* sL, u32* sR, int* shm)
+template <class KT, int WW, class VP = u32*>
+__device__ __forceinline__ int partition_cf_block(KT* K, VP V, int n, u32* sL, u32* sR, int* shm)
 {
 	const int lane = threadIdx.x & 63;
 	const int wv = uni((int)(threadIdx.x >> 6));
@@ -686,8 +687,8 @@ __device__ __forceinline__ int partition_cf_block(KT* K, u32* V, int n, u32* sL,
 // Used where enough independent pieces are in flight to hide that latency.
 // The window [f, l) always holds untouched elements and the literal loop state after
 // the swaps done so far; its last <= 63 elements are finished in registers.
-template <class KT>
-__device__ __forceinline__ int partition_stream(KT* K, u32* V, int first, int last)
+template <class KT, class VP = u32*>
+__device__ __forceinline__ int partition_stream(KT* K, VP V, int first, int last)
 {
 	const int lane = threadIdx.x & 63;
 	first = uni(first); last = uni(last);

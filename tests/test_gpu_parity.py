@@ -366,6 +366,7 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
     monkeypatch.delenv("FG_HIT_BUDGET")
     # 64-bit sort keys (used when record index + position do not fit 32 bits) give the same result
     monkeypatch.setenv("FG_FORCE_KEY64", "1")
+    monkeypatch.setenv("FG_PACKED_KEYS", "0")      # the plain 64-bit key + value form first
     k64 = det.getSeqOverlapsBatch(q, maxOverlaps=11)
     assert (k64.recs.tobytes(), k64.query_off.tobytes(), k64.stats.tobytes()) == base[:3]
     # ... whose LDS pieces are narrowed to 32 bits relative to the piece's minimum when the piece spans
@@ -375,6 +376,20 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
         wide = det.getSeqOverlapsBatch(q, maxOverlaps=11)
         assert (wide.recs.tobytes(), wide.query_off.tobytes(), wide.stats.tobytes()) == base[:3], lim
     monkeypatch.delenv("FG_NARROW_MAX")
+    # ... or packed into ONE 64-bit record per hit (record, curPos, extPos; ordered on the upper bits)
+    monkeypatch.setenv("FG_PACKED_KEYS", "1")
+    for lim in (None, 3_000_000, 0):
+        if lim is not None:
+            monkeypatch.setenv("FG_NARROW_MAX", str(lim))
+        pk = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+        assert (pk.recs.tobytes(), pk.query_off.tobytes(), pk.stats.tobytes(), pk.match_off.tobytes(),
+                pk.matches.tobytes()) == base[:3] + base[6:], lim
+    monkeypatch.setenv("FG_SORT_STREAM_MAX", "600")      # closed-form partitions on the packed records too
+    pk = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+    assert (pk.recs.tobytes(), pk.query_off.tobytes(), pk.stats.tobytes()) == base[:3]
+    monkeypatch.delenv("FG_SORT_STREAM_MAX")
+    monkeypatch.delenv("FG_NARROW_MAX")
+    monkeypatch.delenv("FG_PACKED_KEYS")
     monkeypatch.delenv("FG_FORCE_KEY64")
 
 
