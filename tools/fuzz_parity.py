@@ -55,7 +55,15 @@ def run(seed=0, n_cases=30, verbose=True):
       q = {"fwd": allq[::2], "rc": allq[1::2], "all": allq, "some": rng.choice(allq, size=max(1, rs.n // 2), replace=True)}[qsel].astype(np.uint32)
       det = gpu.OverlapDetector(ctx, vi, int(cfg2["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], keep, dk["only_max_ext"],
                                 maxdiv, dk["nucl_alignment"], part, bool(cfg2["hpc_scoring_on"]))
+      # sort-record form: 32-bit keys where they fit (always, at these sizes), or forced to the packed
+      # 64-bit records / the plain 64-bit keys + values that large inputs use
+      kmode = rng.choice(["auto", "packed", "key64"])
+      os.environ.pop("FG_FORCE_KEY64", None); os.environ.pop("FG_PACKED_KEYS", None)
+      if kmode != "auto":
+          os.environ["FG_FORCE_KEY64"] = "1"
+          os.environ["FG_PACKED_KEYS"] = "1" if kmode == "packed" else "0"
       gres = det.getSeqOverlapsBatch(q, forceLocal=fl, maxOverlaps=mo)
+      os.environ.pop("FG_FORCE_KEY64", None); os.environ.pop("FG_PACKED_KEYS", None)
       ores = o.overlaps(O.detector_params(cfg2, max_divergence=maxdiv, keep_alignment=keep, partition_bad_mappings=part, **dk), q,
                         max_overlaps=mo, force_local=fl)
       same = (gres.lines() == ores.lines() and np.array_equal(gres.query_off, ores.query_off) and
@@ -65,7 +73,7 @@ def run(seed=0, n_cases=30, verbose=True):
               (not part or np.array_equal(gres.needs_trim, ores.needs_trim)))
       tag = "ok " if (same and same_idx) else "BAD"
       if not (same and same_idx): bad += 1
-      if verbose: print(f"{tag} case {case}: {kind}/{preset} k={k} reads={rs.n} {dk} jump={int(cfg2['maximum_jump'])} maxdiv={maxdiv} mo={mo} fl={fl} keep={keep} part={part} q={qsel} "
+      if verbose: print(f"{tag} case {case}: {kind}/{preset} k={k} reads={rs.n} {dk} jump={int(cfg2['maximum_jump'])} maxdiv={maxdiv} mo={mo} fl={fl} keep={keep} part={part} keys={kmode} q={qsel} "
             f"recs={len(gres.recs)} index_same={same_idx}", flush=True)
   print(f"{n_cases} cases, {bad} mismatching, {time.time()-t0:.0f} s")
   return bad
