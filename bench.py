@@ -46,6 +46,8 @@ def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: fl
     base = kernel.split("<")[0]
     if base.startswith("k_chain"):
         base = "k_chain"
+    if base.startswith("k_sort"):       # k_sort_level / k_sort_wide / k_sort_lds share the sort's bytes
+        base = "k_sort_hits"
     return per_bp.get(base, 0.0) * bp
 
 

@@ -6,7 +6,8 @@
 // phase by phase for a whole batch of query reads:
 //   k_probe / k_fill    seed collection                 overlap.cpp:176-196,
 //                       (+ index lookups)               vertex_index.h:139-246
-//   k_sort_hits         std::sort by (extId, curPos)    overlap.cpp:201-204
+//   k_sort_level / _wide / _lds   std::sort by (extId, curPos), exact permutation
+//                                                       overlap.cpp:201-204
 //   k_group_*           equal-extId runs                overlap.cpp:216-234
 //   k_chain             prefilter, optional re-sort by extPos, chaining DP,
 //                       backtrack, overlapTest, primary selection
@@ -15,9 +16,10 @@
 //                       prefix rule, window statistics  overlap.cpp:417-423, :461-506
 //
 // Data layout in HBM: hits are a structure of arrays -- key = extId<<32 | curPos
-// (so the reference's (extId, curPos) comparator is one u64 compare) and
-// val = extPos -- dense per query in the reference's emission order (ascending
-// curPos, per k-mer ascending stored position).
+// (so the reference's (extId, curPos) comparator is one integer compare; packed into
+// 32 bits when record index and position fit, or with extPos into one 64-bit record
+// PK otherwise) and val = extPos -- dense per query in the reference's emission order
+// (ascending curPos, per k-mer ascending stored position).
 #include "fg_ctx.h"
 #include "fg_wavesort.h"
 
@@ -154,8 +156,9 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 // LDS, then the block walks the OUTPUT slots -- thread o finds its owner by bisection of the
 // starts -- so the 12-byte hit records leave as coalesced stores.
 // KT = u64: key = extId << 32 | curPos.  KT = u32 (when record index and position fit 32 bits
-// together): key = record << curBits | curPos -- same order, a third less sort traffic;
-// k_expand_keys restores the 64-bit form after the sort.
+// together): key = record << curBits | curPos -- same order, a third less sort traffic.
+// KT = PK: one 64-bit record per hit (fg_ctx.h), no value array.  Consumers read any of the
+// three through HitKeyView<KT>.
 template <class KT>
 __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
 					   const u64* __restrict__ qKmerOff, int k, u32 firstId, int curBits,
@@ -474,7 +477,7 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	}
 	else
 	{
-	// 64-bit keys (extId << 32 | curPos): a piece of <= 512 hits of one query usually spans few
+	// 64-bit keys (extId << 32 | curPos): a piece of <= SORT_CAP hits of one query usually spans few
 	// target records, so (extId << curBits | curPos) minus the piece's minimum fits 32 bits -- an
 	// order-preserving map, hence the same permutation at the 32-bit kernel's cost.  curBits = 0
 	// (arbitrary keys, fg_debug_sort_pairs): the keys themselves are tried.
