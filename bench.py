@@ -15,8 +15,12 @@ collective (SURVEY.md §8e option A).
 The JSON line also carries
   roofline     for the kernel with the largest device time in the timed region:
                algorithmic bytes (DESIGN.md "Algorithmic bytes") / HIP-event time
-  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on
-               this host's cores on a bounded sample of the same queries, same index.
+  cpu_baseline the reference itself (Flye 2.8.1's own sources compiled into oracle/_ref/ref_dumper,
+               kind "reference") on this host's cores: its index build over all reads, then its
+               overlap stage on a bounded prefix of the same queries, records compared with the GPU's
+  cpu_port     the CPU oracle (oracle/, a port of the reference algorithm) on the same queries
+               against the same (device-built) index; it becomes cpu_baseline when the reference
+               binary is absent.
 """
 from __future__ import annotations
 
@@ -59,9 +63,11 @@ def main():
     ap.add_argument("--scale", type=float, default=None, help="genome scale (default = --gpus)")
     ap.add_argument("--cpu-sample-bp", type=float, default=250e6)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-reference", action="store_true",
-                    help="also time the compiled reference itself (oracle/_ref/ref_dumper: its own index build "
-                         "+ getSeqOverlaps over a bounded prefix of the queries); minutes, off by default")
+    ap.add_argument("--no-cpu-reference", action="store_true",
+                    help="skip the compiled reference itself (oracle/_ref/ref_dumper: its own index build over all "
+                         "reads, ~1 min on 16 cores, + getSeqOverlaps over a bounded prefix of the queries)")
+    ap.add_argument("--cpu-reference-bp", type=float, default=250e6,
+                    help="query prefix (bp) the reference's overlap stage is timed on")
     ap.add_argument("--cpu-reference-threads", type=int, default=0, help="0 = the CPUs this process may use")
     args = ap.parse_args()
 
@@ -103,8 +109,11 @@ def main():
     t_upload = time.time() - t0
     vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
     st = vi.build(cfg)
-    # --min-ovlp of the pipeline driver (N90 rule) = Parameters::minimumOverlap of the assemble stage
-    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=min_ovlp)
+    # --min-ovlp of the pipeline driver (N90 rule) only filters reads by length (main_assemble.cpp:183, done in
+    # workloads.ecoli_pb50) and feeds Extender; the DETECTOR always runs with minimumOverlap = 1000
+    # (main_assemble.cpp:174 overrides the parameter before the detector is built at :229-238)
+    det_min_ovlp = config.DETECTOR_MIN_OVERLAP
+    det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=det_min_ovlp)
     queries = dist.shard_queries(rs.n, rank, world)
     my_bp = int(rs.length[(queries // 2).astype(np.int64)].sum())
 
@@ -157,13 +166,24 @@ def main():
         avg_launch_s = dom_sec / max(1, dom_n)
         alg = algorithmic_bytes(dom_name, res.query_bp, m, d, ovl) / launches_per_step
         achieved = alg / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic = None
+        # PMC traffic (FETCH_SIZE + WRITE_SIZE passes of tools/pmc_traffic.py) cannot be collected inside this
+        # process; the committed figure is used only while it was measured on THESE kernel sources and THIS
+        # detector configuration (stamp written by tools/pmc_traffic.py), otherwise traffic is null
+        traffic, traffic_note = None, "profiles/hbm_traffic.json absent"
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
             try:
-                traffic = json.load(open(prof)).get(dom_name, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+                tj = json.load(open(prof))
+                stamp = tj.get("_stamp", {})
+                if stamp.get("source_sha256") != kernel_source_digest():
+                    traffic_note = "stale: kernel sources changed since the PMC passes"
+                elif stamp.get("min_overlap") != det_min_ovlp:
+                    traffic_note = "stale: PMC passes ran another detector configuration"
+                else:
+                    traffic = tj.get(dom_name, {}).get("bytes_per_launch")
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this source state (profiles/)"
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"unreadable: {e}"
         line = {
             "metric": "Gbp reads overlapped/sec", "value": round(value, 6), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -171,10 +191,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "E.coli PB 50x (synthetic, raw-read cfg): overlap stage, index resident",
                        "genome_bp": int(4_640_000 * scale), "reads": rs.n, "read_bp": rs.total_bases,
-                       "queries_per_rank": int(len(queries)), "min_overlap": min_ovlp, "kmer": int(cfg["kmer_size"]),
+                       "queries_per_rank": int(len(queries)), "min_overlap": det_min_ovlp, "min_read_len": min_ovlp,
+                       "kmer": int(cfg["kmer_size"]),
                        "sharding": f"reads by id over {world} rank(s), index replicated, no collective"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_launch_s * 1e3, 4)},
             "work": {"seed_hits_per_bp": round(m, 4), "dp_elements_per_bp": round(d, 4),
                      "overlaps": int(len(res.recs)), "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
@@ -184,15 +206,38 @@ def main():
                      "upload_s": round(t_upload, 3), "index_entries": int(st["index_entries"])},
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(rs, cfg, vi, queries, args.cpu_sample_bp, min_ovlp)
+            port = cpu_port(rs, cfg, vi, queries, args.cpu_sample_bp, det_min_ovlp)
             # parity on the timed workload itself: the sample's records must match
-            line["cpu_baseline"]["sample_records_identical"] = bool(line["cpu_baseline"].pop("_same")(res))
-            if args.cpu_reference:
-                line["cpu_reference"] = cpu_reference(rs, preset, min_ovlp, queries, res,
-                                                      args.cpu_reference_threads or effective_cpus())
+            port["sample_records_identical"] = bool(port.pop("_same")(res))
+            ref = None
+            if not args.no_cpu_reference:
+                ref = cpu_reference(rs, preset, det_min_ovlp, queries, res,
+                                    args.cpu_reference_threads or effective_cpus(), args.cpu_reference_bp)
+            if ref is not None and "error" not in ref:
+                # the reference itself (Flye's own code on this host's cores) is THE cpu baseline;
+                # the port (oracle/) is reported beside it
+                line["cpu_baseline"] = ref
+                line["cpu_reference"] = ref
+                line["cpu_port"] = port
+            else:
+                line["cpu_baseline"] = port
+                if ref is not None:
+                    line["cpu_reference"] = ref
         print(json.dumps(line), flush=True)
     if world > 1:
         td.destroy_process_group()
+
+
+def kernel_source_digest() -> str:
+    """sha256 over the device sources: what profiles/hbm_traffic.json is stamped with."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "flye_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def effective_cpus() -> int:
@@ -208,7 +253,7 @@ def effective_cpus() -> int:
     return n
 
 
-def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
+def cpu_port(rs, cfg, vi, queries, sample_bp, min_ovlp):
     """The CPU oracle on this host's cores over a bounded sample of the same queries
     against the same index (imported from the device, so the CPU does not spend
     minutes rebuilding it).  Checker/baseline only -- never the measured product."""
@@ -240,10 +285,11 @@ def cpu_baseline(rs, cfg, vi, queries, sample_bp, min_ovlp):
                       f"{dt:.2f} s wall", "_same": same}
 
 
-def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=30e6):
+def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=250e6):
     """The reference itself (Flye 2.8.1 sources compiled by oracle/Makefile, unmodified) on this
     host: reads written as FASTA, its own countKmers + buildIndexUnevenCoverage over ALL reads,
-    then getSeqOverlaps for a prefix of the forward reads through its processInParallel.
+    then getSeqOverlaps for a prefix of the forward reads through its processInParallel; every
+    record of the prefix is compared with the GPU's (floats by bit pattern).
     Checker/baseline only."""
     import tempfile
     from flye_amd import config
@@ -262,13 +308,28 @@ def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=30e6):
         info = O.run_ref(fa, params_string=config.params_string(preset), threads=threads, min_read_len=0,
                          min_overlap=min_ovlp, query_limit=n, ovlp_out=ov)
         wall = time.perf_counter() - t0
-        ref_lines = [l.strip() for l in open(ov) if l.strip() and not l.startswith("#")]
-    end = int(gres.query_off[n])
-    same = gres.lines()[:end] == ref_lines if end < 400000 else None
+        same = records_equal_ref_file(gres.recs[:int(gres.query_off[n])], ov)
     return {"value": round(info["queried_bp"] / info["overlap_s"] / 1e9, 6), "unit": "Gbp/s", "cores": threads,
             "kind": "reference", "overlap_s": info["overlap_s"], "index_s": info["index_s"], "load_s": info["load_s"],
-            "sample": f"first {n} forward reads ({info['queried_bp']} bp); index built by the reference over all reads; "
+            "overlaps": info["overlaps"],
+            "sample": f"first {n} forward reads ({info['queried_bp']} bp) of the same workload through the reference's "
+                      f"processInParallel on {threads} threads; index built by the reference over all reads; "
                       f"{wall:.1f} s wall in total", "gpu_records_identical_to_reference": same}
+
+
+def records_equal_ref_file(recs, path) -> bool:
+    """GPU records against ref_dumper's --ovlp-out text (one OverlapRange per line, the float as
+    its bit pattern in hex), column by column."""
+    import pandas as pd
+    names = ["cur_id", "cur_begin", "cur_end", "cur_len", "ext_id", "ext_begin", "ext_end", "ext_len", "score", "div"]
+    df = pd.read_csv(path, sep=" ", comment="#", header=None, names=names, dtype={"div": str})
+    if len(df) != len(recs):
+        return False
+    for f in names[:-1]:
+        if not np.array_equal(df[f].to_numpy(np.int64), recs[f].astype(np.int64)):
+            return False
+    bits = np.array([int(x, 16) for x in df["div"]], dtype=np.uint32) if len(df) else np.empty(0, np.uint32)
+    return bool(np.array_equal(bits, recs["seq_divergence"].view(np.uint32)))
 
 
 if __name__ == "__main__":

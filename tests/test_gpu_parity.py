@@ -484,15 +484,17 @@ def test_full_size_properties(built):
     key_of_entry = ex.keys[np.searchsorted(ex.key_off, pick.astype(np.uint64), side="right") - 1]
     assert np.array_equal(canon, key_of_entry)
     assert np.array_equal((rv < fw), (rec & 1).astype(bool))    # stored in the canonical orientation
-    # the full all-vs-all pass, twice: deterministic.  minOverlap as the pipeline passes it
-    # (--min-ovlp from the N90 rule, main_assemble.cpp:229-238) -- the bench configuration
-    det.p.min_overlap = min_ovlp
+    # the full all-vs-all pass, twice: deterministic.  The detector runs with minimumOverlap = 1000 whatever
+    # --min-ovlp says (main_assemble.cpp:174, :231; --min-ovlp only filters read length, :183) -- the bench
+    # configuration
+    det_min = config.DETECTOR_MIN_OVERLAP
+    assert det.p.min_overlap == det_min
     allq = np.arange(0, 2 * rs.n, 2, dtype=np.uint32)
     r1 = det.getSeqOverlapsBatch(allq)
     r2 = det.getSeqOverlapsBatch(allq)
     assert r1.recs.tobytes() == r2.recs.tobytes() and len(r1.recs) > 100_000
     rr = r1.recs
-    assert np.all(rr["cur_end"] - rr["cur_begin"] >= min_ovlp) and np.all(rr["ext_end"] - rr["ext_begin"] >= min_ovlp)
+    assert np.all(rr["cur_end"] - rr["cur_begin"] >= det_min) and np.all(rr["ext_end"] - rr["ext_begin"] >= det_min)
     assert np.all(rr["cur_end"] < rr["cur_len"]) and np.all(rr["ext_end"] < rr["ext_len"])
     assert np.all(rr["seq_divergence"] < 1.0)
     # ascending extId inside each query list (reference emission order)
@@ -504,7 +506,7 @@ def test_full_size_properties(built):
     o.import_index(O.IndexExport(ex.keys, ex.key_off, ex.entries, ex.repetitive), vi.getSampleRate())
     sample = np.sort(rng.choice(rs.n, size=300, replace=False))
     sq = (2 * sample).astype(np.uint32)
-    ores = o.overlaps(O.detector_params(cfg, min_overlap=min_ovlp), sq)
+    ores = o.overlaps(O.detector_params(cfg, min_overlap=det_min), sq)
     want = ores.lines()
     got = []
     for i in sample:
@@ -513,10 +515,10 @@ def test_full_size_properties(built):
         got += [f"{p['cur_id']} {p['cur_begin']} {p['cur_end']} {p['cur_len']} {p['ext_id']} {p['ext_begin']} "
                 f"{p['ext_end']} {p['ext_len']} {p['score']} {bits[j]:08x}" for j, p in enumerate(part)]
     assert got == want
-    # and with the detector's default minOverlap = 1000 (more, noisier groups reach the DP)
-    det.p.min_overlap = 1000
-    loose = det.getSeqOverlapsBatch(sq[:120])
-    assert len(loose.recs) > 0 and loose.lines() == o.overlaps(O.detector_params(cfg), sq[:120]).lines()
+    # and with --min-ovlp (the N90 value) as the detector's minOverlap -- what Extender's safeOverlap sees
+    det.p.min_overlap = min_ovlp
+    strict = det.getSeqOverlapsBatch(sq[:120])
+    assert len(strict.recs) > 0 and strict.lines() == o.overlaps(O.detector_params(cfg, min_overlap=min_ovlp), sq[:120]).lines()
 
 
 def test_randomised_parity_sweep(built):

@@ -37,15 +37,21 @@ def main():
     note = sys.argv[4] if len(sys.argv) > 4 else ""
     ft, fc = collect(fdir, "FETCH_SIZE")
     wt, wc = collect(wdir, "WRITE_SIZE")
-    res = {"_note": note}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from flye_amd import config
+    # bench.py only quotes these figures while the kernel sources and the detector configuration are the same
+    res = {"_note": note, "_stamp": {"source_sha256": bench.kernel_source_digest(),
+                                     "min_overlap": config.DETECTOR_MIN_OVERLAP}}
     for k in sorted(set(ft) | set(wt)):
         n = max(fc.get(k, 0), wc.get(k, 0))
         tot = ft.get(k, 0.0) + wt.get(k, 0.0)
         res[k] = {"FETCH_SIZE_bytes": int(ft.get(k, 0)), "WRITE_SIZE_bytes": int(wt.get(k, 0)),
                   "bytes_per_pass": int(tot), "launches_profiled": n, "bytes_per_launch": int(tot / max(1, n))}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    for k, v in sorted(res.items(), key=lambda kv: -(kv[1]["bytes_per_pass"] if isinstance(kv[1], dict) else 0))[:12]:
-        if isinstance(v, dict):
+    for k, v in sorted(res.items(), key=lambda kv: -(kv[1].get("bytes_per_pass", 0) if isinstance(kv[1], dict) else 0))[:12]:
+        if isinstance(v, dict) and "bytes_per_pass" in v:
             print(f"{k:28s} {v['bytes_per_pass'] / 1e9:8.3f} GB/pass  {v['launches_profiled']:3d} launches")
 
 

@@ -9,7 +9,8 @@ rs, min_ovlp, preset = workloads.ecoli_pb50(seed=12345, scale=float(N))
 cfg = config.preset(preset)
 ctx = gpu.Context(int(cfg["kmer_size"]), 0); ctx.set_reads(rs)
 vi = gpu.VertexIndex(ctx, 1.0); st = vi.build(cfg)
-det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=min_ovlp)
+# the assemble stage's detector always runs with minimumOverlap = 1000 (main_assemble.cpp:174, :231)
+det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=config.DETECTOR_MIN_OVERLAP)
 q = dist.shard_queries(rs.n, 0, N)
 bp = int(rs.length[(q // 2).astype(np.int64)].sum())
 det.getSeqOverlapsBatch(q)

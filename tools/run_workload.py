@@ -30,7 +30,8 @@ vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
 st = vi.build(cfg)
 print("index:", {a: st[a] for a in ("selected_kmers", "index_entries", "repetitive_kmers", "repetitive_frequency", "sample_rate")},
       "build %.3f s" % st["build_seconds"], flush=True)
-det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=min_ovlp)
+# the assemble stage's detector always runs with minimumOverlap = 1000 (main_assemble.cpp:174, :231)
+det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg, min_overlap=config.DETECTOR_MIN_OVERLAP)
 if name == "hifi30":
     det.p.max_divergence = cfg["assemble_ovlp_divergence"]
 q = np.arange(0, 2 * rs.n, 2, dtype=np.uint32)
@@ -46,7 +47,7 @@ o.set_reads(rs)
 o.import_index(O.IndexExport(ex.keys, ex.key_off, ex.entries, ex.repetitive), vi.getSampleRate())
 rng = np.random.default_rng(1)
 sample = np.sort(rng.choice(rs.n, size=min(rs.n, int(sys.argv[3]) if len(sys.argv) > 3 else 200), replace=False))
-op = O.detector_params(cfg, min_overlap=min_ovlp, max_divergence=det.p.max_divergence)
+op = O.detector_params(cfg, min_overlap=config.DETECTOR_MIN_OVERLAP, max_divergence=det.p.max_divergence)
 t = time.time(); ores = o.overlaps(op, (2 * sample).astype(np.uint32)); to = time.time() - t
 got = np.concatenate([res.of(int(i)) for i in sample]) if len(sample) else res.recs[:0]
 same = (len(got) == len(ores.recs) and all(np.array_equal(got[f], ores.recs[f]) for f in
