@@ -265,6 +265,17 @@ int fg_debug_sort_pairs(fg_ctx* c, uint64_t* keys, uint32_t* vals, const uint64_
 	});
 }
 
+int fg_debug_edit_distances(fg_ctx* c, uint32_t n_pairs, int use_hpc, int32_t* out_dist, int32_t* out_len_a,
+							int32_t* out_len_b)
+{
+	if (!c || (n_pairs && (!out_dist || !out_len_a || !out_len_b))) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgDebugEditDistances(c, n_pairs, use_hpc, out_dist, out_len_a, out_len_b);
+	});
+}
+
 void fg_release_batch(struct fg_overlap_batch* b)
 {
 	if (!b) return;
@@ -274,7 +285,7 @@ void fg_release_batch(struct fg_overlap_batch* b)
 
 int fg_kernel_times(fg_ctx* c, struct fg_kernel_time* out, int max_entries)
 {
-	if (!c) return FG_ERR_ARG;
+	if (!c || (max_entries > 0 && !out)) return FG_ERR_ARG;
 	int n = (int)c->timer.last.size();
 	for (int i = 0; i < n && i < max_entries; ++i) out[i] = c->timer.last[i];
 	return n;

@@ -101,6 +101,12 @@ struct KernelTimer {
 		if (!enabled) return;
 		HIP_CHECK(hipEventRecord(evs[id].b, stream));
 	}
+	// forget uncollected measurements (a previous call failed half way): the events go back to the pool
+	void reset()
+	{
+		for (auto& ev : evs) { pool.push_back(ev.a); pool.push_back(ev.b); }
+		evs.clear();
+	}
 	// after a stream sync: fold into per-name sums
 	void collect()
 	{
@@ -204,6 +210,9 @@ struct fg_ctx {
 	PinnedBuf<u32> hMatchCnt;
 	DevBuf<char> dSortTasks, dSortBig;
 	DevBuf<int> dEditScratch;
+	DevBuf<u32> dEditList;		// pairs queued for the bit-vector kernel (two lists)
+	DevBuf<char> dEditCnt;
+	DevBuf<u64> dEditSlab;		// per-block string planes + delta planes of the bit-vector kernel
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;
 
@@ -386,5 +395,6 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 				  int curBits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
+void fgDebugEditDistances(fg_ctx* c, u32 nPairs, int useHpc, i32* outDist, i32* outLenA, i32* outLenB);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out);

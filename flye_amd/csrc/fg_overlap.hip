@@ -939,10 +939,15 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
-	c->timer.evs.clear();
+	c->timer.reset();	// a call that failed half way leaves recorded events behind: back to the pool
 	const auto tHost0 = std::chrono::steady_clock::now();
-	hipEvent_t evA, evB;
-	HIP_CHECK(hipEventCreate(&evA)); HIP_CHECK(hipEventCreate(&evB));
+	// the two bracket events come from the timer's pool and go back to it on every exit path
+	struct EvPair {
+		KernelTimer& t; hipEvent_t a, b;
+		explicit EvPair(KernelTimer& t_) : t(t_), a(t_.get()), b(nullptr) { try { b = t_.get(); } catch (...) { t_.pool.push_back(a); throw; } }
+		~EvPair() { t.pool.push_back(a); t.pool.push_back(b); }
+	} evp(c->timer);
+	const hipEvent_t evA = evp.a, evB = evp.b;
 	HIP_CHECK(hipEventRecord(evA, s));
 
 	BatchOwner* own = BatchOwner::acquire();
@@ -969,7 +974,6 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		out->query_off = own->queryOff.data(); out->div_stats_off = own->statOff.data();
 		if (p->keep_alignment) { own->matchOff.assign(1, 0); out->match_off = own->matchOff.data(); }
 		if (p->partition_bad_mappings) { own->needsTrim.assign(1, 0); out->needs_trim = own->needsTrim.data(); }
-		HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 		return;
 	}
 	if (getenv("FG_ABLATE"))
@@ -1195,7 +1199,6 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	float ms = 0;
 	HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
 	out->device_seconds = ms * 1e-3;
-	HIP_CHECK(hipEventDestroy(evA)); HIP_CHECK(hipEventDestroy(evB));
 	c->timer.collect();
 	const auto tHost2 = std::chrono::steady_clock::now();
 	c->timer.last.push_back(fg_kernel_time{"host:launch+sync (wall, includes the device time)",

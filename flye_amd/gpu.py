@@ -37,7 +37,7 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
                "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
-               "fg_kernel_times", "fg_debug_sort_pairs"]
+               "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances"]
 
 
 class FlyeGpuError(RuntimeError):
@@ -113,6 +113,7 @@ def load_library():
         L.fg_release_batch.argtypes = [C.POINTER(OverlapBatch)]
         L.fg_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
         L.fg_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.fg_debug_edit_distances.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         # include/flye_gpu_bridge.h
         L.fgb_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(DetectorParams), C.c_uint32, C.c_uint32]
         L.fgb_destroy.argtypes = [C.c_void_p]
@@ -260,6 +261,16 @@ class Context:
         self._check(self.L.fg_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, off.ctypes.data,
                                                len(off) - 1))
         return k, v
+
+    def debug_edit_distances(self, n_pairs, use_hpc=False):
+        """Device edit-distance kernels on the pairs (read 2i, read 2i+1) of the container;
+        returns (distances, lengths of A, lengths of B)."""
+        d = np.empty(n_pairs, np.int32)
+        la = np.empty(n_pairs, np.int32)
+        lb = np.empty(n_pairs, np.int32)
+        self._check(self.L.fg_debug_edit_distances(self.h, n_pairs, int(bool(use_hpc)), d.ctypes.data,
+                                                   la.ctypes.data, lb.ctypes.data))
+        return d, la, lb
 
     def kernel_times(self):
         arr = (KernelTime * 64)()

@@ -75,6 +75,24 @@ class ReadSet:
         keep = np.nonzero(self.length > min_len)[0]
         return self if len(keep) == self.n else self.subset(keep)
 
+    @staticmethod
+    def from_arrays(seqs) -> "ReadSet":
+        """Reads given as arrays of 0..3 (A, C, G, T), packed like DnaSequence (sequence.h:54-69)."""
+        lens = np.array([len(x) for x in seqs], dtype=np.int32)
+        nw = (lens.astype(np.int64) + 31) // 32
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(nw)
+        words = np.zeros(int(off[-1]), dtype=np.uint64)
+        sh = np.arange(32, dtype=np.uint64) * np.uint64(2)
+        for i, x in enumerate(seqs):
+            if not len(x):
+                continue
+            pad = np.zeros(int(nw[i]) * 32, dtype=np.uint64)
+            pad[:len(x)] = np.asarray(x, dtype=np.uint64) & np.uint64(3)
+            words[int(off[i]):int(off[i + 1])] = (pad.reshape(-1, 32) << sh[None, :]).sum(axis=1, dtype=np.uint64)
+        n = len(seqs)
+        return ReadSet(words, off, lens, np.zeros(n, np.int64), np.zeros(n, np.uint8), int(lens.sum()))
+
     def write_fasta(self, path: str) -> None:
         with open(path, "w") as f:
             for i in range(self.n):

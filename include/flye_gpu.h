@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 2
+#define FG_ABI_VERSION 3
 
 enum {
 	FG_OK = 0,
@@ -197,6 +197,15 @@ int fg_kernel_times(fg_ctx* ctx, struct fg_kernel_time* out, int max_entries);
  * pairs, in place in the caller's host arrays; seg_off has n_seg + 1 entries. */
 int fg_debug_sort_pairs(fg_ctx* ctx, uint64_t* keys, uint32_t* vals,
                         const uint64_t* seg_off, uint32_t n_seg);
+
+/* Test hook: the exact global edit distance (what edlibAlign(NW, TASK_DISTANCE, k = -1) returns,
+ * reference src/sequence/alignment.cpp:233-238, src/sequence/edlib.cpp:141-296) of n_pairs string
+ * pairs through the device kernels of the base-level divergence step.  Pair i = the forward
+ * strands of reads 2i (rows) and 2i+1 (columns) of the container given to fg_set_reads;
+ * use_hpc != 0 compresses homopolymers first (alignment.cpp:52-70).  out_len_a / out_len_b
+ * receive the (compressed) lengths. */
+int fg_debug_edit_distances(fg_ctx* ctx, uint32_t n_pairs, int use_hpc, int32_t* out_dist,
+                            int32_t* out_len_a, int32_t* out_len_b);
 
 #ifdef __cplusplus
 }

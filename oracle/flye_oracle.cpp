@@ -512,8 +512,9 @@ void extractSeq(const Ctx& c, u32 recIdx, int32_t start, int32_t length, bool hp
 }
 
 // exact unit-cost global edit distance (what edlibAlign(NW, DISTANCE, k=-1)
-// returns, edlib.cpp:141-296): Ukkonen band doubling over a plain DP.
-int editDistance(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
+// returns, edlib.cpp:141-296): Ukkonen band doubling over a plain scalar DP.  Kept as the
+// slow, obviously-right form the bit-vector version below is tested against.
+int editDistanceDP(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
 {
 	const int n = (int)a.size(), m = (int)b.size();
 	if (n == 0) return m;
@@ -548,6 +549,72 @@ int editDistance(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b)
 		int d = prev[m];
 		if (d <= kband) return d;
 		kband *= 2;
+	}
+}
+
+// Upper bound D' >= D of the global edit distance of a (rows) and b (columns), with D' == D
+// whenever D <= k: Myers' bit-vector recurrence (Myers 1999, in Hyyro's block form with a
+// horizontal carry in {-1, 0, +1}) over 64-row blocks, each block swept only over the columns
+// its rows can reach on a path of cost <= k (diagonals J - i in [dlo, dhi], Ukkonen).  Cells
+// outside a block's column range count as "reached by +1 steps" from the computed region, so
+// every value is the cost of a real path.  This is the published algorithm edlib implements
+// (edlib.cpp:141-296 drives it with k = 64, 128, ...); the row-block-major sweep with the
+// bottom row's deltas kept in place is our own arrangement (the HIP kernel uses the same one
+// with 64 blocks per wave).
+int editDistanceBand(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b, int k)
+{
+	const int n = (int)a.size(), m = (int)b.size();
+	const int delta = m - n;
+	const int dhi = (k + delta) / 2, dlo = -((k - delta) / 2);	// k >= |delta|
+	std::vector<int8_t> hrow(m, 1);		// D'[r][j+1] - D'[r][j] along the last finished block's bottom row
+	int prevCh = 0;						// columns [0, prevCh) of hrow are computed values, the rest is "+1"
+	long long T = 0;					// D'[r0][cl]
+	for (int r0 = 0; r0 < n; r0 += 64)
+	{
+		const int r1 = std::min(n, r0 + 64), rows = r1 - r0;
+		const int cl = std::max(0, r0 + dlo), ch = std::min(m, r1 + dhi);
+		const int nextCl = r1 < n ? std::max(0, r1 + dlo) : m;
+		u64 peq[4] = {0, 0, 0, 0};
+		for (int i = 0; i < rows; ++i) peq[a[r0 + i] & 3] |= 1ULL << i;
+		u64 Pv = ~0ULL, Mv = 0;
+		long long acc = T + rows;		// D'[r1][cl]: the left boundary is a column of +1 steps
+		const u64 top = 1ULL << (rows - 1);
+		for (int j = cl; j < ch; ++j)
+		{
+			const int hin = j < prevCh ? hrow[j] : 1;
+			u64 Eq = peq[b[j] & 3];
+			const u64 Xv = Eq | Mv;
+			if (hin < 0) Eq |= 1ULL;
+			const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+			u64 Ph = Mv | ~(Xh | Pv);
+			u64 Mh = Pv & Xh;
+			const int hout = ((Ph & top) ? 1 : 0) - ((Mh & top) ? 1 : 0);
+			Ph <<= 1; Mh <<= 1;
+			if (hin < 0) Mh |= 1ULL; else if (hin > 0) Ph |= 1ULL;
+			Pv = Mh | ~(Xv | Ph);
+			Mv = Ph & Xv;
+			hrow[j] = (int8_t)hout;
+			if (j < nextCl) acc += hout;
+		}
+		T = acc;	// D'[r1][nextCl] (r1 == n: D'[n][m])
+		prevCh = ch;
+	}
+	return (int)T;
+}
+
+// the exact distance: band doubling from k0 until the bound is met (edlib.cpp:194-212 starts
+// at 64; any start gives the same value)
+int editDistance(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b, int k0 = 64)
+{
+	const int n = (int)a.size(), m = (int)b.size();
+	if (n == 0) return m;
+	if (m == 0) return n;
+	long long k = std::max(std::max(k0, 1), std::abs(n - m));
+	while (true)
+	{
+		const int d = editDistanceBand(a, b, (int)std::min<long long>(k, n + m));
+		if (d <= k) return d;
+		k *= 2;
 	}
 }
 
@@ -944,6 +1011,18 @@ int fo_edit_distance(const uint8_t* a, int n, const uint8_t* b, int m)
 {
 	std::vector<uint8_t> va(a, a + n), vb(b, b + m);
 	return editDistance(va, vb);
+}
+
+// the same through the plain scalar DP / through the bit-vector form started at band k0
+int fo_edit_distance_dp(const uint8_t* a, int n, const uint8_t* b, int m)
+{
+	std::vector<uint8_t> va(a, a + n), vb(b, b + m);
+	return editDistanceDP(va, vb);
+}
+int fo_edit_distance_k0(const uint8_t* a, int n, const uint8_t* b, int m, int k0)
+{
+	std::vector<uint8_t> va(a, a + n), vb(b, b + m);
+	return editDistance(va, vb, k0);
 }
 
 // ---- introsort emulation self-test against the real std::sort ---------------

@@ -88,6 +88,8 @@ def lib():
         L.fo_fetch_matches.restype = C.c_uint64
         L.fo_fetch_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.fo_edit_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.fo_edit_distance_dp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.fo_edit_distance_k0.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.fo_introsort_mismatches.restype = C.c_int64
         L.fo_introsort_mismatches.argtypes = [C.c_void_p, C.c_int64]
         L.fo_std_sort_perm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
@@ -268,6 +270,36 @@ def edit_distance(a: np.ndarray, b: np.ndarray) -> int:
     a = np.ascontiguousarray(a, np.uint8)
     b = np.ascontiguousarray(b, np.uint8)
     return lib().fo_edit_distance(a.ctypes.data, len(a), b.ctypes.data, len(b))
+
+
+def edit_distance_dp(a: np.ndarray, b: np.ndarray) -> int:
+    """The plain scalar DP (slow; what the bit-vector form is checked against)."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().fo_edit_distance_dp(a.ctypes.data, len(a), b.ctypes.data, len(b))
+
+
+def edit_distance_k0(a: np.ndarray, b: np.ndarray, k0: int) -> int:
+    """The bit-vector form with the band doubling started at k0."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().fo_edit_distance_k0(a.ctypes.data, len(a), b.ctypes.data, len(b), int(k0))
+
+
+def ref_edlib_distances(pairs):
+    """Edit distances of (a, b) pairs of 0..3 arrays through the REFERENCE's edlib
+    (oracle/_ref/ref_dumper --edlib-pairs)."""
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for a, b in pairs:
+            # a leading '^' keeps empty strings parseable as tokens
+            f.write("^" + "".join("ACGT"[x] for x in a) + " ^" + "".join("ACGT"[x] for x in b) + "\n")
+        path = f.name
+    try:
+        out = subprocess.run([REF_DUMPER, "--edlib-pairs", path], check=True, capture_output=True, text=True)
+    finally:
+        os.unlink(path)
+    return [int(x) for x in out.stdout.split()]
 
 
 def introsort_mismatches(keys: np.ndarray) -> int:

@@ -44,6 +44,7 @@
 #include "sequence/overlap.h"
 #include "common/config.h"
 #include "common/parallel.h"
+#include "sequence/edlib.h"
 #undef private
 #undef protected
 
@@ -81,6 +82,23 @@ int main(int argc, char** argv)
 		else if (a == "--nucl-aln") nuclAln = atoi(next().c_str());
 		else if (a == "--keep-aln") keepAln = atoi(next().c_str());
 		else if (a == "--max-div") maxDiv = strtof(next().c_str(), nullptr);
+		else if (a == "--edlib-pairs")
+		{
+			// kernel-level pin of the edit-distance restatements: every line of the file holds two
+			// ACGT strings, each behind a '^' (so that an empty string is still a token); prints what the reference's own call (alignment.cpp:233-238: NW mode,
+			// distance task, k = -1) returns for each pair
+			std::ifstream in(next());
+			std::string qa, qb;
+			while (in >> qa >> qb)
+			{
+				qa.erase(0, 1); qb.erase(0, 1);
+				auto cfg = edlibNewAlignConfig(-1, EDLIB_MODE_NW, EDLIB_TASK_DISTANCE, nullptr, 0);
+				auto res = edlibAlign(qa.c_str(), (int)qa.size(), qb.c_str(), (int)qb.size(), cfg);
+				printf("%d\n", res.editDistance);
+				edlibFreeAlignResult(res);
+			}
+			return 0;
+		}
 		else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
 	}
 	if (!config.empty()) Config::load(config);

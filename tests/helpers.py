@@ -78,3 +78,65 @@ def check_repeat_stage_result(res, case, golden_cases):
     maxd = np.float32(case["max_div"])
     assert np.array_equal(trim, ~(res.recs["seq_divergence"] < maxd))
     assert trim.any() and not trim.all()
+
+
+# ---- edit-distance pairs (tests/golden/edlib_pairs.json) -----------------------------------------
+def edit_pair(spec):
+    """One (a, b) pair of 0..3 arrays from a seeded description: b is a copy of a with
+    sub/ins/del errors at rate ``err`` (err >= 1: unrelated random strings); ``hp`` > 0 plants
+    homopolymer runs (for the compressed form)."""
+    rng = np.random.default_rng(spec["seed"])
+    n = spec["n"]
+    a = rng.integers(0, 4, size=n, dtype=np.uint8)
+    if spec.get("hp", 0):
+        for _ in range(spec["hp"]):
+            if n < 4:
+                break
+            p = int(rng.integers(0, max(1, n - 2)))
+            l = int(rng.integers(2, 12))
+            a[p:p + l] = a[p]
+    err = spec["err"]
+    if err >= 1:
+        b = rng.integers(0, 4, size=spec.get("m", n), dtype=np.uint8)
+        return a, b
+    out = []
+    i = 0
+    r = rng.random(size=2 * n + 16)
+    c = rng.integers(0, 4, size=2 * n + 16, dtype=np.uint8)
+    t = 0
+    while i < n:
+        x = r[t]
+        if x < err / 3:                       # substitution
+            out.append((a[i] + 1 + c[t] % 3) & 3)
+            i += 1
+        elif x < 2 * err / 3:                 # insertion
+            out.append(c[t])
+        elif x < err:                         # deletion
+            i += 1
+        else:
+            out.append(a[i])
+            i += 1
+        t += 1
+    b = np.array(out, dtype=np.uint8)
+    if "shift" in spec:                       # unequal lengths: drop a prefix of b
+        b = b[spec["shift"]:]
+    return a, b
+
+
+def hpc(x):
+    """homopolymerCompression (alignment.cpp:52-70) of a 0..3 array."""
+    x = np.asarray(x, np.uint8)
+    if len(x) == 0:
+        return x
+    keep = np.ones(len(x), bool)
+    keep[1:] = x[1:] != x[:-1]
+    return x[keep]
+
+
+def pairs_readset(pairs):
+    """ReadSet whose reads 2i, 2i+1 are the pair's strings (for fg_debug_edit_distances)."""
+    from flye_amd import synth
+    seqs = []
+    for a, b in pairs:
+        seqs += [a, b]
+    return synth.ReadSet.from_arrays(seqs)

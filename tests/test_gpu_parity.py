@@ -531,3 +531,41 @@ def test_randomised_parity_sweep(built):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(seed=5, n_cases=10, verbose=False) == 0
+
+
+def test_repeat_graph_flag_set_within_time_budget(built):
+    """RepeatGraph::build's detector (repeat_graph.cpp:84-93): no overhang test, kmerMatches kept, all
+    primaries, base-level divergence, bad mappings partitioned -- on noisy-overlap input (HiFi-like reads
+    of a small repeat-rich genome, every read against every read) where most chains join unrelated
+    substrings, so that the edit distances run into the thousands.  This is the configuration of the
+    randomised sweep's seed-41 case 9, which took the round-1 oracle 5 minutes; the device side must stay
+    bounded: O(ND) gives up after ED_EMAX rounds, the banded bit-vector kernel finishes the rest."""
+    import time
+    from flye_amd import config, gpu, synth
+    from oracle import oracle as O
+    rs = synth.simulate(seed=4109, genome_len=46_000, coverage=28, kind="hifi", n_homopolymers=30, n_tandems=30,
+                        n_repeat_families=9).filter_min_len(1000)
+    cfg = config.preset("hifi")
+    ctx = gpu.Context(17, 0)
+    ctx.set_reads(rs)
+    vi = gpu.VertexIndex(ctx, 2.0)
+    vi.buildIndexMinimizers(1, 10, cfg["repeat_kmer_rate"])
+    det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), 2000, 0, True, False, 0.3, True, True, True)
+    q = np.arange(0, 2 * rs.n, dtype=np.uint32)
+    det.getSeqOverlapsBatch(q[:4])                      # first-call allocations stay out of the budget
+    t = time.perf_counter()
+    gres = det.getSeqOverlapsBatch(q)
+    dt = time.perf_counter() - t
+    kt = ctx.kernel_times()
+    o = O.Oracle(17)
+    o.set_reads(rs)
+    o.build_index_minimizers(1, 10, cfg["repeat_kmer_rate"])
+    p = O.detector_params(cfg, min_overlap=2000, max_divergence=0.3, only_max_ext=False, max_overhang=0,
+                          nucl_alignment=True, keep_alignment=True, partition_bad_mappings=True)
+    ores = o.overlaps(p, q)
+    assert gres.lines() == ores.lines() and len(gres.recs) > 1000
+    assert np.array_equal(gres.recs["edit_distance"], ores.recs["edit_distance"])
+    assert np.array_equal(gres.needs_trim, ores.needs_trim) and np.array_equal(gres.matches, ores.matches)
+    assert int(gres.recs["edit_distance"].max()) > 512      # beyond ED_EMAX: the bit-vector kernel was needed ...
+    assert "k_edit_myers" in kt
+    assert dt < 5.0, f"{dt:.2f} s for {len(gres.recs)} records: {kt}"   # ... and the pass stays bounded

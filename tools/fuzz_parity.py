@@ -45,11 +45,6 @@ def run(seed=0, n_cases=30, verbose=True):
                   np.float32(gst["sample_rate"]).tobytes() == np.float32(ost["sample_rate"]).tobytes())
       dk = dict(min_overlap=int(rng.choice([100, 500, 1000, 2000])), only_max_ext=bool(rng.integers(0, 2)),
                 max_overhang=int(rng.choice([0, 100, 500, 1500])), nucl_alignment=bool(cfg["reads_base_alignment"]) and bool(rng.integers(0, 2)))
-      if dk["nucl_alignment"] and dk["max_overhang"] == 0:
-          # no overhang test + base-level divergence = an exact edit distance for every local chain of every read
-          # pair, most of them between unrelated substrings (D in the thousands): minutes for the oracle's banded DP
-          # and for the O(ND) kernel alike (known gap 3) -- nothing a sweep of small cases should time
-          dk["max_overhang"] = 500
       cfg2 = dict(cfg); cfg2["maximum_jump"] = float(rng.choice([300, 1500, 1500, 5000])); cfg2["hpc_scoring_on"] = float(rng.integers(0, 2))
       maxdiv = float(np.float32(rng.choice([1.0, 0.3, 0.05])))
       mo = int(rng.choice([0, 0, 3, 25])); fl = bool(rng.integers(0, 2))
@@ -60,6 +55,18 @@ def run(seed=0, n_cases=30, verbose=True):
       q = {"fwd": allq[::2], "rc": allq[1::2], "all": allq, "some": rng.choice(allq, size=max(1, rs.n // 2), replace=True)}[qsel].astype(np.uint32)
       det = gpu.OverlapDetector(ctx, vi, int(cfg2["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], keep, dk["only_max_ext"],
                                 maxdiv, dk["nucl_alignment"], part, bool(cfg2["hpc_scoring_on"]))
+      op = O.detector_params(cfg2, max_divergence=maxdiv, keep_alignment=keep, partition_bad_mappings=part, **dk)
+      # cost bound, by measurement and whatever the flags are: a degenerate index (a few thousand k-mers of
+      # frequency > 100 on HiFi-like reads: hundreds of seed hits per base, 10^4..10^5-hit groups whose DP
+      # scans hundreds of candidates per element) costs the CPU oracle -- and the reference -- minutes per
+      # read.  The oracle is timed on two queries; the query list is cut to what fits the budget.
+      tp = time.time(); o.overlaps(op, q[:2], max_overlaps=mo, force_local=fl); tp = (time.time() - tp) / min(2, len(q))
+      budget = float(os.environ.get("FUZZ_CASE_SECONDS", "40"))
+      cut = ""
+      if tp * len(q) > budget:
+          keepq = max(2, int(budget / tp))
+          cut = f" (queries cut {len(q)} -> {keepq}: {tp:.1f} s per query on the CPU)"
+          q = q[:keepq]
       # sort-record form: 32-bit keys where they fit (always, at these sizes), or forced to the packed
       # 64-bit records / the plain 64-bit keys + values that large inputs use
       kmode = rng.choice(["auto", "packed", "key64"])
@@ -67,10 +74,13 @@ def run(seed=0, n_cases=30, verbose=True):
       if kmode != "auto":
           os.environ["FG_FORCE_KEY64"] = "1"
           os.environ["FG_PACKED_KEYS"] = "1" if kmode == "packed" else "0"
+      tg = time.time()
       gres = det.getSeqOverlapsBatch(q, forceLocal=fl, maxOverlaps=mo)
+      tg = time.time() - tg
       os.environ.pop("FG_FORCE_KEY64", None); os.environ.pop("FG_PACKED_KEYS", None)
-      ores = o.overlaps(O.detector_params(cfg2, max_divergence=maxdiv, keep_alignment=keep, partition_bad_mappings=part, **dk), q,
-                        max_overlaps=mo, force_local=fl)
+      to = time.time()
+      ores = o.overlaps(op, q, max_overlaps=mo, force_local=fl)
+      to = time.time() - to
       same = (gres.lines() == ores.lines() and np.array_equal(gres.query_off, ores.query_off) and
               np.array_equal(gres.stats.view(np.uint32), ores.stats.view(np.uint32)) and
               np.array_equal(gres.recs["edit_distance"], ores.recs["edit_distance"]) and
@@ -79,7 +89,7 @@ def run(seed=0, n_cases=30, verbose=True):
       tag = "ok " if (same and same_idx) else "BAD"
       if not (same and same_idx): bad += 1
       if verbose: print(f"{tag} case {case}: {kind}/{preset} k={k} reads={rs.n} {dk} jump={int(cfg2['maximum_jump'])} maxdiv={maxdiv} mo={mo} fl={fl} keep={keep} part={part} keys={kmode} q={qsel} "
-            f"recs={len(gres.recs)} index_same={same_idx}", flush=True)
+            f"recs={len(gres.recs)} index_same={same_idx} gpu={tg:.2f}s oracle={to:.2f}s{cut}", flush=True)
   print(f"{n_cases} cases, {bad} mismatching, {time.time()-t0:.0f} s")
   return bad
 
