@@ -280,101 +280,126 @@ __device__ __forceinline__ i32 wave_incl_max(i32 v)
 }
 
 // The reference's look-back loop (overlap.cpp:285-316: scan j downwards, keep the first
-// strictly better score, two early exits) runs 64 candidates per step: lane L holds element
-// i-1-L in registers (the window slides one lane per element), an exclusive prefix max in
-// scan order tells every lane whether it would have improved the running best, a ballot of
-// the exit conditions cuts the scan.  The group's columns arrive 64 elements at a time in
-// registers, the results leave the same way; only look-backs deeper than 64 (about 1.6 %
-// of the elements on PacBio-raw data) read memory.
+// strictly better score, two early exits) runs 64 candidates per step, and only for the
+// elements that need it:
+//  * tile = 64 consecutive elements, element 64 T + L on lane L, in registers (cur, ext, score,
+//    back); the previous tile stays in registers too, older ones in a 256-element LDS ring,
+//    anything older in memory;
+//  * an element whose predecessor i-1 lies on the same diagonal less than k ahead takes that
+//    predecessor at once (first candidate of the scan, improves on 0, triggers the early exit,
+//    overlap.cpp:301-307): score[i] = score[i-1] + (cur[i] - cur[i-1]), back[i] = i-1.  Such
+//    elements form RUNS behind a head element; they are found for the whole tile in parallel
+//    and get their scores by one vector add when their head is known -- 64 % of the elements
+//    at the bench workload never enter the serial loop;
+//  * a head at lane il scans elements i-1 .. i-64 = lanes il-1 .. 0 of its own tile, then lanes
+//    63 .. il of the previous one: candidate scores are computed in place, rotated into scan
+//    order through the LDS crossbar (one ds_bpermute), an exclusive prefix max (DPP row shifts
+//    + row broadcasts) tells every candidate whether it would have improved the running best,
+//    ballots of the exit conditions cut the scan.  The "beyond maxJump" exit is monotone along
+//    the scan (the group is sorted by the coordinate it tests), so its position is a popcount.
+//    Look-backs deeper than 64 take 64 more candidates per step from the ring / memory.
 #ifndef DP_WAVES
-#define DP_WAVES 1	// one group per block: a block's slot frees as soon as ITS group is done (1 / 2 / 4 / 8 waves
-					// per block measured: 12.3 / 13.4 / 13.8 / 14.1 ms)
+#define DP_WAVES 1	// one group per block: a block's slot frees as soon as ITS group is done
 #endif
 #ifndef DP_RING
 #define DP_RING 256
 #endif
-__global__ void __launch_bounds__(DP_WAVES * 64)
-k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
-		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-		   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-		   const uint8_t* __restrict__ groupExtSorted,
-		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
-		   i32* __restrict__ gScore, i32* __restrict__ gBack)
+
+// one 64-candidate step of the scan.  ns: candidate scores in SCAN order (lane 0 = first scanned),
+// I32_MIN where the candidate is out of range; mA: scan-order mask of "same diagonal, closer than
+// k" candidates; rhoB: scan position of the first candidate beyond the window (64 = none).
+// Updates (maxScore, maxId); returns true when the scan ends inside this step.
+__device__ __forceinline__ bool dp_scan_step(i32 ns, u64 mA, int rhoB, i32 firstJ, i32& maxScore, i32& maxId)
+{
+	const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
+	const u64 updM = __builtin_amdgcn_ballot_w64(ns > exc);
+	const u64 stopM = (updM & mA) | (rhoB < 64 ? (1ULL << rhoB) : 0ULL);
+	const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
+	const u64 um = updM & lim;
+	if (um)
+	{
+		const int lu = 63 - __clzll(um);
+		maxScore = __builtin_amdgcn_readlane(ns, __builtin_amdgcn_readfirstlane(lu));
+		maxId = firstJ - lu;
+	}
+	return stopM != 0;
+}
+
+template <bool EXTS>
+__device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i32 n, const u32* __restrict__ cur,
+										 const u32* __restrict__ ext, i32* __restrict__ score, i32* __restrict__ back,
+										 i32* ringC, i32* ringE, i32* ringS)
 {
 	const int lane = threadIdx.x & 63;
-	const u32 li = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
-	if (li >= nList) return;
-	const u64 g = fg_uni(list[li]);
-	const u64 g0 = fg_uni(groupStart[g]);
-	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
-	const i32 n = (i32)(gend - g0);
-	const bool extSorted = fg_uni((u32)groupExtSorted[g]) != 0;	// decided by k_group_prep
-	const u32* cur = gCur + g0;
-	const u32* ext = gExt + g0;
-	i32* score = gScore + g0;
-	i32* back = gBack + g0;
-	const int k = P.k;
-	const i32 maxJump = P.maxJump;
-
-	// tile = 64 consecutive elements, one per lane; results of the tile; next tile prefetched.
-	// Completed tiles are also kept in a per-wave LDS ring (the last DP_RING elements) so that
-	// look-backs deeper than the register window rarely touch global memory.
-	__shared__ i32 ring[DP_WAVES][3][DP_RING];
-	i32* ringC = ring[threadIdx.x >> 6][0];
-	i32* ringE = ring[threadIdx.x >> 6][1];
-	i32* ringS = ring[threadIdx.x >> 6][2];
-	i32 tc = lane < n ? (i32)cur[lane] : 0, te = lane < n ? (i32)ext[lane] : 0;
-	i32 ntc = 64 + lane < n ? (i32)cur[64 + lane] : 0, nte = 64 + lane < n ? (i32)ext[64 + lane] : 0;
-	// The results of a tile are not gathered per element: the score window `ws` (and a back
-	// pointer window `wb` shifted along with it) holds elements i-1 .. i-64 on lanes 0 .. 63, so at
-	// a tile boundary the tile's results are the windows read in reverse lane order.
-	i32 rs = 0, rb = -1;
-	i32 wc = tc, we = te, ws = 0, wb = -1;	// window for i = 1: only lane 0 (element 0: score 0, no predecessor) is meaningful
-	i32 prevC = __builtin_amdgcn_readlane(tc, 0), prevE = __builtin_amdgcn_readlane(te, 0), prevS = 0;
-	for (i32 i = 1; i < n; ++i)
+	i32 pc = 0, pe = 0, ps = 0;		// previous tile
+	i32 ntc = lane < n ? (i32)cur[lane] : 0, nte = lane < n ? (i32)ext[lane] : 0;
+	for (i32 tb0 = 0; tb0 < n; tb0 += 64)
 	{
-		if ((i & 63) == 0)
+		const i32 tc = ntc, te = nte;
+		ntc = tb0 + 64 + lane < n ? (i32)cur[tb0 + 64 + lane] : 0;
+		nte = tb0 + 64 + lane < n ? (i32)ext[tb0 + 64 + lane] : 0;
+		const bool valid = tb0 + lane < n;
+		// last element of the previous tile (meaningless for the first tile: elements 0 and 1 are never fast)
+		const i32 pcl = __builtin_amdgcn_readlane(pc, 63), pel = __builtin_amdgcn_readlane(pe, 63),
+				  psl = __builtin_amdgcn_readlane(ps, 63);
+		const i32 dc0 = tc - wave_shr1(tc, pcl), de0 = te - wave_shr1(te, pel);
+		const bool fast = valid && dc0 == de0 && (u32)(dc0 - 1) < (u32)(min(k, maxJump) - 1) && tb0 + lane >= 2;
+		u64 headM = __builtin_amdgcn_ballot_w64(valid && !fast);
+		// nearest head at or below every lane (-1: the run started in an earlier tile)
+		const i32 hl = wave_incl_max(fast ? -1 : lane);
+		const i32 chead = __builtin_amdgcn_ds_bpermute(max(hl, 0) << 2, tc);
+		const i32 off = tc - (hl >= 0 ? chead : pcl);
+		i32 ts = psl + off;				// right for the leading run; the others are set when their head is done
+		i32 tbk = tb0 + lane - 1;		// right for every run element
+		if (tb0 == 0)
 		{
-			const i32 tb = i - 64;
-			rs = __shfl(ws, 63 - lane); rb = __shfl(wb, 63 - lane);
-			score[tb + lane] = rs; back[tb + lane] = rb;
-			ringC[(tb + lane) & (DP_RING - 1)] = tc; ringE[(tb + lane) & (DP_RING - 1)] = te; ringS[(tb + lane) & (DP_RING - 1)] = rs;
-			tc = ntc; te = nte;
-			ntc = i + 64 + lane < n ? (i32)cur[i + 64 + lane] : 0;
-			nte = i + 64 + lane < n ? (i32)ext[i + 64 + lane] : 0;
+			// element 0: score 0, no predecessor, never scanned for (overlap.cpp:266-267, :277)
+			ts = lane == 0 ? 0 : ts;
+			tbk = lane == 0 ? -1 : tbk;
+			headM &= ~1ULL;
 		}
-		const int il = __builtin_amdgcn_readfirstlane(i & 63);
-		const i32 cn = __builtin_amdgcn_readlane(tc, il), en = __builtin_amdgcn_readlane(te, il);
-		i32 maxScore = 0, maxId = 0;
-		bool done = false;
+		while (headM)
 		{
-			// scalar fast path: the predecessor i-1 lies on the same diagonal less than k ahead.
-			// It is the first candidate of the scan, improves on 0 (its score is >= 0) and
-			// triggers the reference's early exit at once (overlap.cpp:301-307).
-			// (element i-1's position and score are still in scalar registers from the last step)
-			const i32 dc0 = cn - prevC;
-			if (dc0 == en - prevE && dc0 > 0 && dc0 < k && dc0 < maxJump)
+			const int il = __builtin_amdgcn_readfirstlane(__ffsll((long long)headM) - 1);
+			headM &= headM - 1;
+			const i32 i = tb0 + il;
+			const i32 cn = __builtin_amdgcn_readlane(tc, il), en = __builtin_amdgcn_readlane(te, il);
+			i32 maxScore = 0, maxId = 0;
+			bool done;
 			{
-				maxScore = prevS + dc0;
-				maxId = i - 1;
-				done = true;
-			}
-		}
-		for (i32 jb = i - 1; jb >= 0 && !done; jb -= 64)
-		{
-			const i32 j = jb - lane;
-			const bool valid = j >= 0;
-			i32 cp = wc, ep = we, sj = ws;
-			if (jb != i - 1)
-			{
-				// deeper than the register window: the previous DP_RING elements from LDS,
-				// anything older from memory (stored by this wave)
-				// (j <= i - 65 < tileBase: never inside the current tile)
-				const i32 tileBase = i & ~63;
-				cp = 0; ep = 0; sj = 0;
-				if (valid)
+				// candidates i-1 .. i-64 in place: lanes below il hold this tile's elements, the others the previous tile's
+				const bool own = lane < il;
+				const i32 cp = own ? tc : pc, ep = own ? te : pe, sj = own ? ts : ps;
+				const bool exists = own || tb0 > 0;
+				const i32 dc = cn - cp, de = en - ep;
+				const bool inr = exists && max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
+				const i32 jd = abs(dc - de);
+				i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
+				asm volatile("" : "+v"(nsRaw));	// keep the arithmetic out of a conditional block
+				const i32 ns = inr ? nsRaw : I32_MIN;
+				const u64 mB = __builtin_amdgcn_ballot_w64(!exists || (EXTS ? de : dc) > maxJump);
+				const u64 mAn = __builtin_amdgcn_ballot_w64(inr && jd == 0 && dc < k);
+				// scan order: position r <- lane (il - 1 - r) mod 64
+				const i32 nsR = __builtin_amdgcn_ds_bpermute(((il - 1 - lane) & 63) << 2, ns);
+				u64 mA = 0;
+				if (mAn)
 				{
-					if (j >= tileBase - DP_RING)
+					const u64 R = __brevll(mAn);
+					const int sh = (64 - il) & 63;
+					mA = sh ? (R >> sh) | (R << (64 - sh)) : R;
+				}
+				done = dp_scan_step(nsR, mA, __popcll(~mB), i - 1, maxScore, maxId);
+			}
+			for (i32 jb = i - 65; jb >= 0 && !done; jb -= 64)
+			{
+				// deeper: lane = scan position; the previous DP_RING elements of finished tiles from LDS,
+				// anything older from memory (stored by this wave)
+				const i32 j = jb - lane;
+				const bool exists = j >= 0;
+				i32 cp = 0, ep = 0, sj = 0;
+				if (exists)
+				{
+					if (j >= tb0 - DP_RING)
 					{
 						cp = ringC[j & (DP_RING - 1)]; ep = ringE[j & (DP_RING - 1)]; sj = ringS[j & (DP_RING - 1)];
 					}
@@ -385,43 +410,50 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 						sj = __hip_atomic_load(&score[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					}
 				}
+				const i32 dc = cn - cp, de = en - ep;
+				const bool inr = exists && max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
+				const i32 jd = abs(dc - de);
+				i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
+				asm volatile("" : "+v"(nsRaw));
+				const i32 ns = inr ? nsRaw : I32_MIN;
+				const u64 mB = __builtin_amdgcn_ballot_w64(!exists || (EXTS ? de : dc) > maxJump);
+				const u64 mA = __builtin_amdgcn_ballot_w64(inr && jd == 0 && dc < k);
+				done = dp_scan_step(ns, mA, __popcll(~mB), jb, maxScore, maxId);
 			}
-			// straight-line (no exec-mask branches): unsigned range tests, selects
-			const i32 dc = cn - cp, de = en - ep;
-			const bool inr = valid && (u32)(dc - 1) < (u32)(maxJump - 1) && (u32)(de - 1) < (u32)(maxJump - 1);
-			const i32 jd = abs(dc - de);
-			i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
-			asm volatile("" : "+v"(nsRaw));	// keep the arithmetic out of a conditional block
-			const i32 ns = inr ? nsRaw : I32_MIN;
-			const i32 gapSel = extSorted ? de : dc;
-			const bool brkB = valid && gapSel > maxJump;
-			const bool brkA = inr && jd == 0 && dc < k;
-			const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
-			const bool upd = inr && ns > exc;
-			const u64 stopM = __builtin_amdgcn_ballot_w64(brkB || (upd && brkA));
-			const u64 updM = __builtin_amdgcn_ballot_w64(upd);
-			const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
-			const u64 um = updM & lim;
-			if (um)
-			{
-				const int lu = 63 - __clzll(um);
-				maxScore = __builtin_amdgcn_readlane(ns, __builtin_amdgcn_readfirstlane(lu));
-				maxId = jb - lu;
-			}
-			if (stopM || ((P.ablate & 1) != 0)) done = true;
+			const i32 sNew = max(maxScore, k);
+			ts = hl == il ? sNew + off : ts;	// the head (off = 0) and its run inside this tile
+			tbk = lane == il ? (maxScore > k ? maxId : -1) : tbk;
 		}
-		const i32 sNew = max(maxScore, k);
-		wc = wave_shr1(wc, cn); we = wave_shr1(we, en); ws = wave_shr1(ws, sNew);
-		wb = wave_shr1(wb, maxScore > k ? maxId : -1);
-		prevC = cn; prevE = en; prevS = sNew;
+		if (valid)
+		{
+			score[tb0 + lane] = ts; back[tb0 + lane] = tbk;
+			ringC[(tb0 + lane) & (DP_RING - 1)] = tc; ringE[(tb0 + lane) & (DP_RING - 1)] = te; ringS[(tb0 + lane) & (DP_RING - 1)] = ts;
+		}
+		pc = tc; pe = te; ps = ts;
 	}
-	{
-		// last (partial) tile: element tb + L sits on lane n-1-tb-L of the windows
-		const i32 tb = (n - 1) & ~63;
-		const i32 src = (n - 1 - tb - lane) & 63;
-		rs = __shfl(ws, src); rb = __shfl(wb, src);
-		if (tb + lane < n) { score[tb + lane] = rs; back[tb + lane] = rb; }
-	}
+}
+
+__global__ void __launch_bounds__(DP_WAVES * 64)
+k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+		   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+		   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
+		   const uint8_t* __restrict__ groupExtSorted,
+		   const u32* __restrict__ gCur, const u32* __restrict__ gExt,
+		   i32* __restrict__ gScore, i32* __restrict__ gBack)
+{
+	const u32 li = blockIdx.x * DP_WAVES + (threadIdx.x >> 6);
+	if (li >= nList) return;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
+	const i32 n = (i32)(gend - g0);
+	const bool extSorted = fg_uni((u32)groupExtSorted[g]) != 0;	// decided by k_group_prep
+	__shared__ i32 ring[DP_WAVES][3][DP_RING];
+	i32* ringC = ring[threadIdx.x >> 6][0];
+	i32* ringE = ring[threadIdx.x >> 6][1];
+	i32* ringS = ring[threadIdx.x >> 6][2];
+	if (extSorted) dp_group<true>(P.k, P.maxJump, n, gCur + g0, gExt + g0, gScore + g0, gBack + g0, ringC, ringE, ringS);
+	else dp_group<false>(P.k, P.maxJump, n, gCur + g0, gExt + g0, gScore + g0, gBack + g0, ringC, ringE, ringS);
 }
 
 // ---- finish ------------------------------------------------------------------------------
