@@ -311,7 +311,8 @@ __device__ __forceinline__ i32 wave_incl_max(i32 v)
 // Updates (maxScore, maxId); returns true when the scan ends inside this step.
 __device__ __forceinline__ bool dp_scan_step(i32 ns, u64 mA, int rhoB, i32 firstJ, i32& maxScore, i32& maxId)
 {
-	const i32 exc = max(wave_incl_max(wave_shr1(ns, I32_MIN)), maxScore);
+	// exclusive prefix: the shift fills lane 0 with 0, which the max with maxScore (>= 0) absorbs
+	const i32 exc = max(wave_incl_max(__builtin_amdgcn_update_dpp(0, ns, 0x138, 0xf, 0xf, true)), maxScore);
 	const u64 updM = __builtin_amdgcn_ballot_w64(ns > exc);
 	const u64 stopM = (updM & mA) | (rhoB < 64 ? (1ULL << rhoB) : 0ULL);
 	const u64 lim = stopM ? (((stopM & (0 - stopM)) << 1) - 1) : ~0ULL;
@@ -325,13 +326,26 @@ __device__ __forceinline__ bool dp_scan_step(i32 ns, u64 mA, int rhoB, i32 first
 	return stopM != 0;
 }
 
+// |a - b| of two values read as unsigned (one instruction; the operands are in-range distances
+// whenever the result is used)
+__device__ __forceinline__ u32 abs_diff(i32 a, i32 b)
+{
+	u32 r;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 template <bool EXTS>
 __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i32 n, const u32* __restrict__ cur,
 										 const u32* __restrict__ ext, i32* __restrict__ score, i32* __restrict__ back,
 										 i32* ringC, i32* ringE, i32* ringS)
 {
 	const int lane = threadIdx.x & 63;
-	i32 pc = 0, pe = 0, ps = 0;		// previous tile
+	const i32 negLane4 = (-1 - lane) * 4;
+	// "no such element" (the tile before the first, positions before the group's start): coordinates so far
+	// away that the candidate is out of range and beyond the window by the ordinary tests
+	const i32 FAR = -(1 << 30);
+	i32 pc = FAR, pe = FAR, ps = 0;		// previous tile
 	i32 ntc = lane < n ? (i32)cur[lane] : 0, nte = lane < n ? (i32)ext[lane] : 0;
 	for (i32 tb0 = 0; tb0 < n; tb0 += 64)
 	{
@@ -370,17 +384,18 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 				// candidates i-1 .. i-64 in place: lanes below il hold this tile's elements, the others the previous tile's
 				const bool own = lane < il;
 				const i32 cp = own ? tc : pc, ep = own ? te : pe, sj = own ? ts : ps;
-				const bool exists = own || tb0 > 0;
 				const i32 dc = cn - cp, de = en - ep;
-				const bool inr = exists && max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
-				const i32 jd = abs(dc - de);
+				const bool inr = max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
+				const i32 jd = (i32)abs_diff(dc, de);
 				i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
 				asm volatile("" : "+v"(nsRaw));	// keep the arithmetic out of a conditional block
 				const i32 ns = inr ? nsRaw : I32_MIN;
-				const u64 mB = __builtin_amdgcn_ballot_w64(!exists || (EXTS ? de : dc) > maxJump);
-				const u64 mAn = __builtin_amdgcn_ballot_w64(inr && jd == 0 && dc < k);
+				// every mask is one bare compare; they are combined as scalars
+				const u64 inrM = __builtin_amdgcn_ballot_w64(inr);
+				const u64 mB = __builtin_amdgcn_ballot_w64((EXTS ? de : dc) > maxJump);
+				const u64 mAn = __builtin_amdgcn_ballot_w64(dc == de) & __builtin_amdgcn_ballot_w64(dc < k) & inrM;
 				// scan order: position r <- lane (il - 1 - r) mod 64
-				const i32 nsR = __builtin_amdgcn_ds_bpermute(((il - 1 - lane) & 63) << 2, ns);
+				const i32 nsR = __builtin_amdgcn_ds_bpermute((il * 4 + negLane4) & 0xfc, ns);
 				u64 mA = 0;
 				if (mAn)
 				{
@@ -395,9 +410,8 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 				// deeper: lane = scan position; the previous DP_RING elements of finished tiles from LDS,
 				// anything older from memory (stored by this wave)
 				const i32 j = jb - lane;
-				const bool exists = j >= 0;
-				i32 cp = 0, ep = 0, sj = 0;
-				if (exists)
+				i32 cp = FAR, ep = FAR, sj = 0;
+				if (j >= 0)
 				{
 					if (j >= tb0 - DP_RING)
 					{
@@ -411,13 +425,14 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 					}
 				}
 				const i32 dc = cn - cp, de = en - ep;
-				const bool inr = exists && max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
-				const i32 jd = abs(dc - de);
+				const bool inr = max((u32)(dc - 1), (u32)(de - 1)) < (u32)(maxJump - 1);
+				const i32 jd = (i32)abs_diff(dc, de);
 				i32 nsRaw = sj + min(min(dc, de), k) - (jd > 100 ? 2 * jd : (jd >> 1));
 				asm volatile("" : "+v"(nsRaw));
 				const i32 ns = inr ? nsRaw : I32_MIN;
-				const u64 mB = __builtin_amdgcn_ballot_w64(!exists || (EXTS ? de : dc) > maxJump);
-				const u64 mA = __builtin_amdgcn_ballot_w64(inr && jd == 0 && dc < k);
+				const u64 inrM = __builtin_amdgcn_ballot_w64(inr);
+				const u64 mB = __builtin_amdgcn_ballot_w64((EXTS ? de : dc) > maxJump);
+				const u64 mA = __builtin_amdgcn_ballot_w64(dc == de) & __builtin_amdgcn_ballot_w64(dc < k) & inrM;
 				done = dp_scan_step(ns, mA, __popcll(~mB), jb, maxScore, maxId);
 			}
 			const i32 sNew = max(maxScore, k);
