@@ -30,6 +30,19 @@ void BatchOwner::release(BatchOwner* b)
 
 namespace {
 
+// Initialising the HIP runtime draws from libc's rand() stream (measured: tools/rand_stream_probe.py; only
+// the first runtime initialisation of a process does).  The reference picks the reads of
+// estimateOverlaperParameters with rand() (overlap.cpp:752-756, also sequence_container.cpp:318-328,
+// chimera.cpp:76) and never seeds it, so a host program that creates a context first would see other
+// picks.  While this guard lives the process draws from a private state array; the caller's stream
+// continues exactly where it was (glibc keeps the position inside the state array it hands back).
+struct RandStreamGuard {
+	char buf[128];
+	char* old;
+	RandStreamGuard() { old = initstate(1u, buf, sizeof(buf)); }
+	~RandStreamGuard() { if (old) setstate(old); }
+};
+
 template <class F>
 int guarded(fg_ctx* c, F f)
 {
@@ -69,6 +82,7 @@ int fg_create(fg_ctx** out, int device, int kmer_size)
 	if (!out) return FG_ERR_ARG;
 	*out = nullptr;
 	if (kmer_size < 1 || kmer_size > 32) return FG_ERR_KMER_SIZE;
+	RandStreamGuard keepCallersRandStream;
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FG_ERR_NO_DEVICE;
 	if (device < 0 || device >= count) return FG_ERR_NO_DEVICE;
@@ -93,6 +107,16 @@ void fg_destroy(fg_ctx* ctx)
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
 	delete ctx;
+}
+
+int fg_container_info(const fg_ctx* c, uint32_t* first_id, uint32_t* n_fwd, uint32_t* query_first_id, uint32_t* query_n_fwd)
+{
+	if (!c) return FG_ERR_ARG;
+	if (first_id) *first_id = c->firstId;
+	if (n_fwd) *n_fwd = c->nReads;
+	if (query_first_id) *query_first_id = c->hasQ ? c->qFirstId : 0;
+	if (query_n_fwd) *query_n_fwd = c->hasQ ? c->nQReads : 0;
+	return FG_OK;
 }
 
 int fg_set_reads(fg_ctx* c, uint32_t n, const uint64_t* words, const uint64_t* word_off,

@@ -3,7 +3,9 @@
 //
 // Mirrors the query side of the reference's OverlapContainer (src/sequence/overlap.cpp:
 // 518-574): lazySeqOverlaps = cached forward list + complemented twin, quickSeqOverlaps =
-// uncached, with the caller's maxOverlaps / forceLocal.
+// uncached, with the caller's maxOverlaps / forceLocal; fgb_quick_ex = one getSeqOverlaps call
+// (overlap.cpp:99-508) with everything it returns for that read, also for records of a container
+// the device does not hold (their sequence travels with the request).
 #include "../../include/flye_gpu_bridge.h"
 
 #include <atomic>
@@ -15,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -41,10 +44,20 @@ struct Entry {	// one forward read of the lazy cache (IndexVecWrapper, overlap.h
 	RecList fwd, rev;
 };
 
+// everything one getSeqOverlaps call returns for one read
+struct ReadResult {
+	RecList recs;
+	std::vector<uint64_t> matchOff;
+	std::vector<int32_t> matches;
+	std::vector<uint8_t> trim;
+	std::vector<float> stats;
+};
+
 struct QuickReq {
 	uint32_t id; int32_t maxOverlaps; uint8_t forceLocal;
+	const uint64_t* words = nullptr; int32_t len = 0;	// foreign record: its sequence
 	bool done = false; int status = FG_OK;
-	RecList out;
+	std::unique_ptr<ReadResult> res;
 };
 
 } // namespace
@@ -53,10 +66,11 @@ struct fgb_container {
 	fg_ctx* ctx = nullptr;
 	fg_detector_params params;
 	uint32_t maxBatch = 4096, lingerUs = 200;
+	uint32_t firstId = 0, nFwd = 0, qFirstId = 0, qNFwd = 0;	// id ranges of the context's containers
 
 	std::mutex mu;
 	std::condition_variable cvWork, cvDone;
-	std::unordered_map<uint32_t, std::unique_ptr<Entry>> cache;	// by forward id
+	std::unordered_map<uint32_t, std::shared_ptr<Entry>> cache;	// by forward id (waiters hold the entry too)
 	std::deque<uint32_t> lazyQ;		// forward ids somebody waits for
 	std::deque<uint32_t> prefetchQ;	// forward ids nobody waits for yet
 	std::deque<QuickReq*> quickQ;
@@ -67,19 +81,38 @@ struct fgb_container {
 
 	void run();
 	int deviceCall(const fg_detector_params& p, const std::vector<uint32_t>& ids, int32_t mo, uint8_t fl,
-				   std::vector<RecList>& lists, std::vector<float>& st);
+				   std::vector<std::unique_ptr<ReadResult>>& out);
+	// a query id the device call would accept (fg_overlaps rejects the whole batch otherwise)
+	bool validQueryId(uint32_t id) const
+	{
+		const uint32_t base = qNFwd ? qFirstId : firstId, cnt = qNFwd ? qNFwd : nFwd;
+		return id >= base && id - base < 2 * cnt;
+	}
+	bool inIndexed(uint32_t id) const { return id >= firstId && id - firstId < 2 * nFwd; }
 };
 
 int fgb_container::deviceCall(const fg_detector_params& p, const std::vector<uint32_t>& ids, int32_t mo, uint8_t fl,
-							  std::vector<RecList>& lists, std::vector<float>& st)
+							  std::vector<std::unique_ptr<ReadResult>>& out)
 {
 	fg_overlap_batch b;
 	const int rc = fg_overlaps(ctx, &p, ids.data(), (uint32_t)ids.size(), mo, fl, &b);
 	if (rc != FG_OK) return rc;
-	lists.resize(ids.size());
+	out.resize(ids.size());
 	for (size_t i = 0; i < ids.size(); ++i)
-		lists[i].assign(b.recs + b.query_off[i], b.recs + b.query_off[i + 1]);
-	st.assign(b.div_stats, b.div_stats + b.n_div_stats);
+	{
+		std::unique_ptr<ReadResult> r(new ReadResult);
+		const uint64_t a = b.query_off[i], e = b.query_off[i + 1];
+		r->recs.assign(b.recs + a, b.recs + e);
+		if (b.match_off)
+		{
+			r->matchOff.resize(e - a + 1);
+			for (uint64_t j = a; j <= e; ++j) r->matchOff[j - a] = b.match_off[j] - b.match_off[a];
+			r->matches.assign(b.matches + 2 * b.match_off[a], b.matches + 2 * b.match_off[e]);
+		}
+		if (b.needs_trim) r->trim.assign(b.needs_trim + a, b.needs_trim + e);
+		r->stats.assign(b.div_stats + b.div_stats_off[i], b.div_stats + b.div_stats_off[i + 1]);
+		out[i] = std::move(r);
+	}
 	fg_release_batch(&b);
 	return FG_OK;
 }
@@ -106,20 +139,22 @@ void fgb_container::run()
 			prefetchQ.pop_front();
 			auto it = cache.find(id);
 			if (it != cache.end()) continue;	// asked for (and queued) or computed meanwhile
-			cache.emplace(id, std::unique_ptr<Entry>(new Entry));
+			cache.emplace(id, std::make_shared<Entry>());
 			ids.push_back(id);
 		}
 		if (!ids.empty())
 		{
 			const fg_detector_params p = params;
 			lk.unlock();
-			std::vector<RecList> lists; std::vector<float> st;
-			const int rc = deviceCall(p, ids, 0, 0, lists, st);
+			std::vector<std::unique_ptr<ReadResult>> res;
+			const int rc = deviceCall(p, ids, 0, 0, res);
 			std::vector<RecList> revs(rc == FG_OK ? ids.size() : 0);
+			std::vector<float> st;
 			for (size_t i = 0; i < revs.size(); ++i)
 			{
-				revs[i].reserve(lists[i].size());
-				for (const auto& o : lists[i]) revs[i].push_back(complement(o));
+				revs[i].reserve(res[i]->recs.size());
+				for (const auto& o : res[i]->recs) revs[i].push_back(complement(o));
+				st.insert(st.end(), res[i]->stats.begin(), res[i]->stats.end());
 			}
 			lk.lock();
 			++stats.device_calls; stats.reads_computed += ids.size();
@@ -129,25 +164,25 @@ void fgb_container::run()
 				e.status = rc;
 				if (rc == FG_OK)
 				{
-					e.fwd.swap(lists[i]); e.rev.swap(revs[i]);
+					e.fwd.swap(res[i]->recs); e.rev.swap(revs[i]);
 					e.fwd.shrink_to_fit(); e.rev.shrink_to_fit();
 					stats.cached_overlaps += e.fwd.size();
 				}
-				e.ready = true;
+				e.ready = true;		// a failed entry is handed to its waiters, who then drop it (fgb_lazy)
 			}
 			divStats.insert(divStats.end(), st.begin(), st.end());
 			cvDone.notify_all();
 		}
 
-		// ---- quick requests, one device call per (maxOverlaps, forceLocal) class ----
+		// ---- quick requests: one device call per (maxOverlaps, forceLocal, native / foreign) class ----
 		if (!quickQ.empty())
 		{
-			std::map<std::pair<int32_t, uint8_t>, std::vector<QuickReq*>> classes;
+			std::map<std::tuple<int32_t, uint8_t, bool>, std::vector<QuickReq*>> classes;
 			size_t taken = 0;
 			while (!quickQ.empty() && taken < maxBatch)
 			{
 				QuickReq* r = quickQ.front(); quickQ.pop_front(); ++taken;
-				classes[{r->maxOverlaps, r->forceLocal}].push_back(r);
+				classes[std::make_tuple(r->maxOverlaps, r->forceLocal, r->words != nullptr)].push_back(r);
 			}
 			const fg_detector_params p = params;
 			lk.unlock();
@@ -155,17 +190,43 @@ void fgb_container::run()
 			size_t calls = 0, reads = 0;
 			for (auto& kv : classes)
 			{
+				const bool foreign = std::get<2>(kv.first);
+				std::vector<QuickReq*>& reqs = kv.second;
 				std::vector<uint32_t> qids;
-				for (QuickReq* r : kv.second) qids.push_back(r->id);
-				std::vector<RecList> lists; std::vector<float> st;
-				const int rc = deviceCall(p, qids, kv.first.first, kv.first.second, lists, st);
-				++calls; reads += qids.size();
-				for (size_t i = 0; i < kv.second.size(); ++i)
+				int rc = FG_OK;
+				if (foreign)
 				{
-					kv.second[i]->status = rc;
-					if (rc == FG_OK) kv.second[i]->out.swap(lists[i]);
+					// the waiting foreign records become a temporary query container; their device ids
+					// lie behind the indexed container's and are mapped back afterwards
+					std::vector<uint64_t> words, off(1, 0);
+					std::vector<int32_t> len;
+					for (QuickReq* r : reqs)
+					{
+						const size_t nw = ((size_t)r->len + 31) / 32;
+						words.insert(words.end(), r->words, r->words + nw);
+						off.push_back(words.size());
+						len.push_back(r->len);
+					}
+					uint32_t base = firstId + 2 * nFwd;
+					if ((uint64_t)base + 2ULL * reqs.size() > 0xFFFFFFFFULL) base = 0;	// room below the indexed ids instead
+					if (words.empty()) words.push_back(0);
+					rc = fg_set_queries(ctx, (uint32_t)reqs.size(), words.data(), off.data(), len.data(), base);
+					for (size_t i = 0; i < reqs.size(); ++i) qids.push_back(base + 2 * (uint32_t)i);
 				}
-				allSt.insert(allSt.end(), st.begin(), st.end());
+				else
+					for (QuickReq* r : reqs) qids.push_back(r->id);
+				std::vector<std::unique_ptr<ReadResult>> res;
+				if (rc == FG_OK) rc = deviceCall(p, qids, std::get<0>(kv.first), std::get<1>(kv.first), res);
+				if (foreign) (void)fg_set_queries(ctx, 0, nullptr, nullptr, nullptr, 0);
+				++calls; reads += qids.size();
+				for (size_t i = 0; i < reqs.size(); ++i)
+				{
+					reqs[i]->status = rc;
+					if (rc != FG_OK) continue;
+					if (foreign) for (auto& o : res[i]->recs) o.cur_id = reqs[i]->id;
+					allSt.insert(allSt.end(), res[i]->stats.begin(), res[i]->stats.end());
+					reqs[i]->res = std::move(res[i]);
+				}
 			}
 			lk.lock();
 			stats.device_calls += calls; stats.reads_computed += reads;
@@ -181,21 +242,34 @@ void fgb_container::run()
 	cvDone.notify_all();
 }
 
+static int quickCommon(fgb_container* c, QuickReq& r)
+{
+	std::unique_lock<std::mutex> lk(c->mu);
+	++c->stats.requests;
+	if (c->stop) return FG_ERR_STATE;
+	c->quickQ.push_back(&r);
+	c->cvWork.notify_one();
+	c->cvDone.wait(lk, [&] { return r.done; });
+	return r.status;
+}
+
 extern "C" {
 
 int fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params* params,
 			   uint32_t max_batch, uint32_t linger_us)
 {
 	if (!out || !ctx || !params) return FG_ERR_ARG;
-	if (params->keep_alignment || params->partition_bad_mappings) return FG_ERR_UNSUPPORTED;
 	try
 	{
-		fgb_container* c = new fgb_container;
+		std::unique_ptr<fgb_container> c(new fgb_container);
 		c->ctx = ctx; c->params = *params;
 		c->maxBatch = max_batch ? max_batch : 4096;
 		c->lingerUs = linger_us;
-		c->worker = std::thread([c] { c->run(); });
-		*out = c;
+		const int rc = fg_container_info(ctx, &c->firstId, &c->nFwd, &c->qFirstId, &c->qNFwd);
+		if (rc != FG_OK) return rc;
+		fgb_container* raw = c.release();
+		raw->worker = std::thread([raw] { raw->run(); });
+		*out = raw;
 		return FG_OK;
 	}
 	catch (...) { return FG_ERR_NOMEM; }
@@ -213,6 +287,9 @@ void fgb_destroy(fgb_container* c)
 int fgb_lazy(fgb_container* c, uint32_t read_id, const struct fg_overlap_rec** recs, uint64_t* n)
 {
 	if (!c || !recs || !n) return FG_ERR_ARG;
+	if (c->params.keep_alignment || c->params.partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	// a bad id is this caller's error alone: it never reaches a batch (fg_overlaps rejects a batch as a whole)
+	if (!c->validQueryId(read_id)) return FG_ERR_ARG;
 	const uint32_t fwd = read_id & ~1u;	// forward records have even ids (sequence_container.h:27-33)
 	std::unique_lock<std::mutex> lk(c->mu);
 	++c->stats.requests;
@@ -220,14 +297,20 @@ int fgb_lazy(fgb_container* c, uint32_t read_id, const struct fg_overlap_rec** r
 	auto it = c->cache.find(fwd);
 	if (it == c->cache.end())
 	{
-		it = c->cache.emplace(fwd, std::unique_ptr<Entry>(new Entry)).first;
+		it = c->cache.emplace(fwd, std::make_shared<Entry>()).first;
 		c->lazyQ.push_back(fwd);
 		c->cvWork.notify_one();
 	}
 	else if (it->second->ready) ++c->stats.cache_hits;
-	Entry* e = it->second.get();
+	const std::shared_ptr<Entry> e = it->second;
 	c->cvDone.wait(lk, [&] { return e->ready; });
-	if (e->status != FG_OK) return e->status;
+	if (e->status != FG_OK)
+	{
+		// failures are not cached: the entry leaves the map (its waiters keep it alive), a later request retries
+		auto cur = c->cache.find(fwd);
+		if (cur != c->cache.end() && cur->second == e) c->cache.erase(cur);
+		return e->status;
+	}
 	const RecList& l = (read_id & 1u) ? e->rev : e->fwd;
 	*recs = l.data(); *n = l.size();
 	return FG_OK;
@@ -237,25 +320,53 @@ int fgb_quick(fgb_container* c, uint32_t read_id, int32_t max_overlaps, uint8_t 
 			  struct fg_overlap_rec* out, uint64_t cap, uint64_t* n)
 {
 	if (!c || !n || (cap && !out) || max_overlaps < 0) return FG_ERR_ARG;
-	QuickReq r{read_id, max_overlaps, (uint8_t)(force_local ? 1 : 0)};
-	{
-		std::unique_lock<std::mutex> lk(c->mu);
-		++c->stats.requests;
-		if (c->stop) return FG_ERR_STATE;
-		c->quickQ.push_back(&r);
-		c->cvWork.notify_one();
-		c->cvDone.wait(lk, [&] { return r.done; });
-	}
-	if (r.status != FG_OK) return r.status;
-	*n = r.out.size();
-	const uint64_t m = r.out.size() < cap ? r.out.size() : cap;
-	if (m) memcpy(out, r.out.data(), m * sizeof(fg_overlap_rec));
+	if (c->params.keep_alignment || c->params.partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	if (!c->validQueryId(read_id)) return FG_ERR_ARG;
+	QuickReq r; r.id = read_id; r.maxOverlaps = max_overlaps; r.forceLocal = (uint8_t)(force_local ? 1 : 0);
+	const int rc = quickCommon(c, r);
+	if (rc != FG_OK) return rc;
+	*n = r.res->recs.size();
+	const uint64_t m = r.res->recs.size() < cap ? r.res->recs.size() : cap;
+	if (m) memcpy(out, r.res->recs.data(), m * sizeof(fg_overlap_rec));
 	return FG_OK;
+}
+
+int fgb_quick_ex(fgb_container* c, uint32_t read_id, const uint64_t* words, int32_t len,
+				 int32_t max_overlaps, uint8_t force_local, struct fgb_result* out)
+{
+	if (!c || !out || max_overlaps < 0 || (words && len < 0)) return FG_ERR_ARG;
+	memset(out, 0, sizeof(*out));
+	if (c->params.partition_bad_mappings && max_overlaps != 0) return FG_ERR_UNSUPPORTED;
+	if (words && c->qNFwd) return FG_ERR_STATE;	// the temporary query container would replace the caller's own
+	if (words ? c->inIndexed(read_id) : !c->validQueryId(read_id)) return FG_ERR_ARG;
+	QuickReq r; r.id = read_id; r.maxOverlaps = max_overlaps; r.forceLocal = (uint8_t)(force_local ? 1 : 0);
+	r.words = words; r.len = len;
+	const int rc = quickCommon(c, r);
+	if (rc != FG_OK) return rc;
+	ReadResult* res = r.res.release();
+	out->n = res->recs.size();
+	out->recs = res->recs.data();
+	if (c->params.keep_alignment) { out->match_off = res->matchOff.data(); out->matches = res->matches.data(); }
+	if (c->params.partition_bad_mappings) out->needs_trim = res->trim.data();
+	out->n_div_stats = res->stats.size();
+	out->div_stats = res->stats.data();
+	out->owner_ = res;
+	return FG_OK;
+}
+
+void fgb_release_result(struct fgb_result* r)
+{
+	if (!r) return;
+	delete (ReadResult*)r->owner_;
+	memset(r, 0, sizeof(*r));
 }
 
 int fgb_prefetch(fgb_container* c, const uint32_t* read_ids, uint32_t n)
 {
 	if (!c || (n && !read_ids)) return FG_ERR_ARG;
+	if (c->params.keep_alignment || c->params.partition_bad_mappings) return FG_ERR_UNSUPPORTED;
+	for (uint32_t i = 0; i < n; ++i)
+		if (!c->validQueryId(read_ids[i])) return FG_ERR_ARG;
 	std::lock_guard<std::mutex> g(c->mu);
 	for (uint32_t i = 0; i < n; ++i)
 	{

@@ -35,7 +35,7 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
                       ("hpc_len_cur", "<i4"), ("hpc_len_ext", "<i4")])
 
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
-               "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
+               "fg_container_info", "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
                "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances"]
 

@@ -54,6 +54,11 @@ const char* fg_strerror(int code);
 const char* fg_last_error(const fg_ctx* ctx);
 int  fg_abi_version(void);
 
+/* Id range of the indexed container and of the optional query container (n_fwd forward records
+ * each, ids first_id + 2i and their reverse complements + 1); any pointer may be NULL. */
+int fg_container_info(const fg_ctx* ctx, uint32_t* first_id, uint32_t* n_fwd,
+                      uint32_t* query_first_id, uint32_t* query_n_fwd);
+
 /* SequenceContainer contents (src/sequence/sequence_container.cpp:48-79,
  * :359-392).  Forward strands only; the reverse complement of read i is
  * implied (FastaRecord::Id first_seq_id + 2i is the forward record, +1 its

@@ -30,8 +30,10 @@ typedef struct fgb_container fgb_container;
 
 /* ctx must have its index built and must not be used directly by the caller while
  * the container lives.  params is copied (max_divergence can be changed later with
- * fgb_set_divergence_threshold).  keep_alignment / partition_bad_mappings are
- * passed through to fg_overlaps; their extra arrays are not cached (FG_ERR_UNSUPPORTED). */
+ * fgb_set_divergence_threshold).  keep_alignment / partition_bad_mappings are passed
+ * through to fg_overlaps; their extra arrays (kmerMatches, needs_trim) come back through
+ * fgb_quick_ex only -- fgb_lazy / fgb_quick / fgb_prefetch answer FG_ERR_UNSUPPORTED on a
+ * container created with either flag. */
 int  fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params* params,
                 uint32_t max_batch, uint32_t linger_us);
 void fgb_destroy(fgb_container* c);
@@ -45,6 +47,34 @@ int fgb_lazy(fgb_container* c, uint32_t read_id, const struct fg_overlap_rec** r
  * 518-526): not cached.  Writes at most cap records, *n is the full count. */
 int fgb_quick(fgb_container* c, uint32_t read_id, int32_t max_overlaps, uint8_t force_local,
               struct fg_overlap_rec* out, uint64_t cap, uint64_t* n);
+
+/* OverlapDetector::getSeqOverlaps(fastaRec, forceLocal, divStats, maxOverlaps)
+ * (overlap.cpp:99-508) for ONE record, as the reference's OverlapContainer calls it from many
+ * threads (overlap.cpp:518-526, :547-551): everything of the result that belongs to this read --
+ * records, kmerMatches (keep_alignment), needs_trim marks (partition_bad_mappings: the caller runs
+ * its own checkIdyAndTrim on those, overlap.cpp:474-485) and the values getSeqOverlaps appends to
+ * OvlpDivStats (:500-506).  Not cached.
+ *
+ * words == NULL: read_id is a record of the indexed container (or of the fg_set_queries one).
+ * words != NULL: the record lives in a container the device does not hold (reads against graph
+ * edges, read_aligner.cpp:178-217): its sequence -- len bases as given, DnaSequence packing
+ * (sequence.h:54-69: 32 nt per uint64, nt j at bits (j%32)*2) -- travels with the request; the
+ * dispatcher uploads the waiting foreign records of a batch as a temporary query container.
+ * read_id is only used to label the records (cur_id) and must not be an id of the indexed container.
+ * The arrays stay valid until fgb_release_result(). */
+struct fgb_result {
+	uint64_t n;                         /* overlaps */
+	const struct fg_overlap_rec* recs;
+	const uint64_t* match_off;          /* keep_alignment: n + 1 offsets, in pairs */
+	const int32_t* matches;             /* (cur, ext) pairs */
+	const uint8_t* needs_trim;          /* partition_bad_mappings: n marks */
+	uint64_t n_div_stats;
+	const float* div_stats;
+	void* owner_;
+};
+int fgb_quick_ex(fgb_container* c, uint32_t read_id, const uint64_t* words, int32_t len,
+                 int32_t max_overlaps, uint8_t force_local, struct fgb_result* out);
+void fgb_release_result(struct fgb_result* r);
 
 /* Hint: these reads will be asked for (e.g. Extender::assembleDisjointigs warming the
  * cache over all forward reads, extender.cpp:363-382).  Returns at once; the lists are

@@ -315,6 +315,15 @@ def std_sort_perm(keys: np.ndarray) -> np.ndarray:
 
 
 # --- the compiled reference ---------------------------------------------------
+REF_DUMPER_GPU = os.path.join(_HERE, "_ref", "ref_dumper_gpu")
+
+
+def have_ref_gpu() -> bool:
+    """oracle/_ref/ref_dumper_gpu: the same dumper with the reference's getSeqOverlaps / index build
+    replaced at link time by integration/flye_seam.cpp (the compiled Flye-side binding)."""
+    return os.path.exists(REF_DUMPER_GPU)
+
+
 def have_ref() -> bool:
     return os.path.exists(REF_DUMPER)
 
@@ -322,8 +331,8 @@ def have_ref() -> bool:
 def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, max_overlaps=0,
             force_local=False, min_overlap=1000, div_mode="none", index_out=None, ovlp_out=None,
             query_limit=None, rc_queries=False, queries_fasta=None, only_max=None, max_overhang=None,
-            nucl_aln=None, keep_aln=False, max_div=None):
-    cmd = [REF_DUMPER, "--reads", fasta, "--threads", str(threads), "--min-read-len", str(min_read_len),
+            nucl_aln=None, keep_aln=False, max_div=None, find_all=False, partition_bad=False, binary=None, env=None):
+    cmd = [binary or REF_DUMPER, "--reads", fasta, "--threads", str(threads), "--min-read-len", str(min_read_len),
            "--max-overlaps", str(max_overlaps), "--force-local", str(int(force_local)),
            "--min-overlap", str(min_overlap), "--div-mode", div_mode]
     if params_string:
@@ -350,7 +359,11 @@ def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, m
         cmd += ["--keep-aln", "1"]
     if max_div is not None:
         cmd += ["--max-div", repr(float(max_div))]
-    out = subprocess.run(cmd, check=True, capture_output=True, text=True)
+    if find_all:
+        cmd += ["--find-all"]
+    if partition_bad:
+        cmd += ["--partition-bad", "1"]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env)
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 

@@ -53,12 +53,12 @@ static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 int main(int argc, char** argv)
 {
 	std::string reads, queriesFile, params, config, indexOut, ovlpOut, divMode = "none";
-	int onlyMax = 1, maxOverhang = -1, nuclAln = -1, keepAln = 0;
+	int onlyMax = 1, maxOverhang = -1, nuclAln = -1, keepAln = 0, partitionBad = 0;
 	float maxDiv = 1.0f;
 	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
 	int minOverlap = 1000;	// main_assemble.cpp:174
 	long queryLimit = -1;
-	bool rcQueries = false;
+	bool rcQueries = false, findAll = false;
 	for (int i = 1; i < argc; ++i)
 	{
 		std::string a = argv[i];
@@ -76,11 +76,13 @@ int main(int argc, char** argv)
 		else if (a == "--ovlp-out") ovlpOut = next();
 		else if (a == "--query-limit") queryLimit = atol(next().c_str());
 		else if (a == "--rc-queries") rcQueries = true;
+		else if (a == "--find-all") findAll = true;	// OverlapContainer::findAllOverlaps (overlap.cpp:625-665)
 		else if (a == "--queries") queriesFile = next();	// second container (ReadAligner-style)
 		else if (a == "--only-max") onlyMax = atoi(next().c_str());
 		else if (a == "--max-overhang") maxOverhang = atoi(next().c_str());
 		else if (a == "--nucl-aln") nuclAln = atoi(next().c_str());
 		else if (a == "--keep-aln") keepAln = atoi(next().c_str());
+		else if (a == "--partition-bad") partitionBad = atoi(next().c_str());
 		else if (a == "--max-div") maxDiv = strtof(next().c_str(), nullptr);
 		else if (a == "--edlib-pairs")
 		{
@@ -182,7 +184,7 @@ int main(int argc, char** argv)
 						 /*store alignment*/ (bool)keepAln, /*only max*/ (bool)onlyMax,
 						 /*div threshold*/ maxDiv,
 						 nuclAln >= 0 ? (bool)nuclAln : (bool)Config::get("reads_base_alignment"),
-						 /*partition bad*/ false,
+						 /*partition bad*/ (bool)partitionBad,
 						 (bool)Config::get("hpc_scoring_on"));
 	OverlapContainer readOverlaps(ovlp, qc);
 	float meanDiv = 0.0f;
@@ -195,6 +197,36 @@ int main(int argc, char** argv)
 		meanDiv = readOverlaps._meanTrueOvlpDiv;
 	}
 	auto t3 = clk::now();
+
+	if (findAll)
+	{
+		// the repeat stage's use (repeat_graph.cpp:96-99): every forward sequence through lazySeqOverlaps,
+		// ensureTransitivity(false), filterOverlaps -- all reference code above getSeqOverlaps.  The stored
+		// lists are printed per sequence with their lines sorted: the order inside a list depends on the
+		// iteration order of a concurrently filled hash table (overlap.cpp:580-585), i.e. on thread timing.
+		readOverlaps.findAllOverlaps();
+		FILE* f = ovlpOut.empty() ? stdout : fopen(ovlpOut.c_str(), "w");
+		size_t total = 0;
+		for (const auto& seq : qc.iterSeqs())
+		{
+			std::vector<std::string> lines;
+			for (auto& o : readOverlaps.lazySeqOverlaps(seq.id))
+			{
+				char buf[256];
+				snprintf(buf, sizeof(buf), "%u %d %d %d %u %d %d %d %d %08x %zu", o.curId._id, o.curBegin, o.curEnd, o.curLen,
+						 o.extId._id, o.extBegin, o.extEnd, o.extLen, o.score, fbits(o.seqDivergence),
+						 o.kmerMatches ? o.kmerMatches->size() : (size_t)0);
+				lines.push_back(buf);
+			}
+			std::sort(lines.begin(), lines.end());
+			fprintf(f, "# seq %u: %zu overlaps\n", seq.id._id, lines.size());
+			for (auto& l : lines) fprintf(f, "%s\n", l.c_str());
+			total += lines.size();
+		}
+		if (f != stdout) fclose(f);
+		printf("{\"find_all_overlaps\": %zu, \"threads\": %d}\n", total, threads);
+		return 0;
+	}
 
 	std::vector<FastaRecord::Id> queries;
 	for (const auto& seq : qc.iterSeqs())

@@ -104,3 +104,16 @@ def test_graft_entry_build_passes(built):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.build()
+
+
+@pytest.mark.gpu
+def test_context_creation_leaves_libc_rand_stream_alone(built):
+    """HIP runtime initialisation draws from libc's rand(); fg_create shields the caller's stream, which
+    the reference relies on for the reads estimateOverlaperParameters picks (overlap.cpp:752-756).
+    Runs in a fresh process so that this really is the first runtime initialisation."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from flye_amd import gpu; libc = ctypes.CDLL(None); "
+            "libc.srand(1); c = gpu.Context(17, 0); print(libc.rand())") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True)
+    assert int(out.stdout.split()[-1]) == 1804289383     # glibc: first value of the stream seeded with 1
