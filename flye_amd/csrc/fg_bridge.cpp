@@ -11,6 +11,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -392,6 +394,81 @@ uint64_t fgb_divergence_stats(fgb_container* c, float* out, uint64_t cap)
 	const uint64_t m = c->divStats.size() < cap ? c->divStats.size() : cap;
 	if (out && m) memcpy(out, c->divStats.data(), m * sizeof(float));
 	return c->divStats.size();
+}
+
+// ---- on-disk text forms -----------------------------------------------------------------------
+int64_t fg_overlap_dump(const struct fg_overlap_rec* r, const char* cur_name, const char* ext_name, char* buf, uint64_t cap)
+{
+	if (!r || !cur_name || !ext_name || (cap && !buf)) return FG_ERR_ARG;
+	// operator<<(float) = %g with precision 6 on the value converted to double (overlap.h:227-236)
+	const int n = snprintf(buf, (size_t)cap, "%s %d %d %d %s %d %d %d -1 -1 %d %g", cur_name, r->cur_begin, r->cur_end,
+						   r->cur_len, ext_name, r->ext_begin, r->ext_end, r->ext_len, r->score, (double)r->seq_divergence);
+	return n;
+}
+
+int fg_overlap_load(const char* line, struct fg_overlap_rec* r, uint32_t* cur_name_off, uint32_t* cur_name_len,
+					uint32_t* ext_name_off, uint32_t* ext_name_len)
+{
+	if (!line || !r || !cur_name_off || !cur_name_len || !ext_name_off || !ext_name_len) return FG_ERR_ARG;
+	memset(r, 0, sizeof(*r));
+	// operator>> semantics (overlap.h:238-251): whitespace-separated tokens
+	const char* p = line;
+	auto token = [&](uint32_t& off, uint32_t& len) -> bool
+	{
+		while (*p == ' ' || *p == '\t') ++p;
+		if (!*p || *p == '\n') return false;
+		off = (uint32_t)(p - line);
+		while (*p && *p != ' ' && *p != '\t' && *p != '\n') ++p;
+		len = (uint32_t)(p - line) - off;
+		return true;
+	};
+	auto integer = [&](int32_t& v) -> bool
+	{
+		uint32_t o, l;
+		if (!token(o, l)) return false;
+		char* end = nullptr;
+		const long x = strtol(line + o, &end, 10);
+		if (end != line + o + l) return false;
+		v = (int32_t)x;
+		return true;
+	};
+	int32_t ph1, ph2;
+	if (!token(*cur_name_off, *cur_name_len) || !integer(r->cur_begin) || !integer(r->cur_end) || !integer(r->cur_len) ||
+		!token(*ext_name_off, *ext_name_len) || !integer(r->ext_begin) || !integer(r->ext_end) || !integer(r->ext_len) ||
+		!integer(ph1) || !integer(ph2) || !integer(r->score))
+		return FG_ERR_ARG;
+	uint32_t o, l;
+	if (!token(o, l)) return FG_ERR_ARG;
+	char* end = nullptr;
+	r->seq_divergence = strtof(line + o, &end);		// istream >> float
+	if (end != line + o + l) return FG_ERR_ARG;
+	return FG_OK;
+}
+
+int64_t fg_alignment_dump(int64_t edge_id, const struct fg_overlap_rec* r, const char* read_name, const char* edge_name,
+						  char* buf, uint64_t cap)
+{
+	if (!r || !read_name || !edge_name || (cap && !buf)) return FG_ERR_ARG;
+	const int head = snprintf(buf, (size_t)cap, "\tAln\t%lld\t", (long long)edge_id);
+	const uint64_t used = (uint64_t)head < cap ? (uint64_t)head : cap;
+	const int64_t rest = fg_overlap_dump(r, read_name, edge_name, buf ? buf + used : buf, cap - used);
+	return rest < 0 ? rest : head + rest;
+}
+
+int64_t fg_fasta_record(const char* name, const uint64_t* words, int32_t len, char* buf, uint64_t cap)
+{
+	if (!name || len < 0 || (len && !words) || (cap && !buf)) return FG_ERR_ARG;
+	const uint64_t nameLen = strlen(name);
+	const uint64_t need = 1 + nameLen + 1 + (uint64_t)len + ((uint64_t)len + 79) / 80;
+	if (need > cap) return (int64_t)need;
+	char* o = buf;
+	*o++ = '>'; memcpy(o, name, nameLen); o += nameLen; *o++ = '\n';
+	for (int32_t i = 0; i < len; ++i)
+	{
+		*o++ = "ACGT"[(words[i >> 5] >> ((i & 31) * 2)) & 3];
+		if (i % 80 == 79 || i == len - 1) *o++ = '\n';
+	}
+	return (int64_t)(o - buf);
 }
 
 void fgb_get_stats(fgb_container* c, struct fgb_stats* out)

@@ -125,6 +125,14 @@ def load_library():
         L.fgb_divergence_stats.restype = C.c_uint64
         L.fgb_divergence_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.fgb_get_stats.argtypes = [C.c_void_p, C.POINTER(BridgeStats)]
+        # on-disk text forms (host only)
+        L.fg_overlap_dump.restype = C.c_int64
+        L.fg_overlap_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.fg_overlap_load.argtypes = [C.c_char_p, C.c_void_p] + [C.POINTER(C.c_uint32)] * 4
+        L.fg_alignment_dump.restype = C.c_int64
+        L.fg_alignment_dump.argtypes = [C.c_int64, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+        L.fg_fasta_record.restype = C.c_int64
+        L.fg_fasta_record.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_uint64]
         _LIB = L
     return _LIB
 
@@ -368,6 +376,68 @@ class OverlapDetector:
         self.ctx._check(L.fg_overlaps(self.ctx.h, C.byref(self.p), q.ctypes.data, len(q), maxOverlaps,
                                       int(bool(forceLocal)), C.byref(b)))
         return OverlapResult(L, q, b)
+
+
+def seq_name(read_names, first_id, rec_id) -> str:
+    """SequenceContainer::seqName: '+' / '-' + the FASTA header (sequence_container.cpp:62, :75)."""
+    i = int(rec_id) - int(first_id)
+    return ("-" if i & 1 else "+") + read_names[i >> 1]
+
+
+def dump_overlaps(recs: np.ndarray, cur_name, ext_name, edge_ids=None):
+    """OverlapRange::dump (overlap.h:227-236) of every record; ``cur_name`` / ``ext_name`` map a record id
+    to its container name.  With ``edge_ids`` the lines take ReadAligner::storeAlignments' form
+    (read_aligner.cpp:333-335)."""
+    L = load_library()
+    buf = C.create_string_buffer(1024)
+    out = []
+    recs = np.ascontiguousarray(recs)
+    for i in range(len(recs)):
+        r = recs[i:i + 1]
+        cn, en = cur_name(r["cur_id"][0]).encode(), ext_name(r["ext_id"][0]).encode()
+        if edge_ids is None:
+            n = L.fg_overlap_dump(r.ctypes.data, cn, en, buf, len(buf))
+        else:
+            n = L.fg_alignment_dump(int(edge_ids[i]), r.ctypes.data, cn, en, buf, len(buf))
+        if n < 0:
+            raise FlyeGpuError(int(n), "fg_overlap_dump")
+        if n >= len(buf):
+            buf = C.create_string_buffer(int(n) + 1)
+            continue_n = (L.fg_overlap_dump(r.ctypes.data, cn, en, buf, len(buf)) if edge_ids is None else
+                          L.fg_alignment_dump(int(edge_ids[i]), r.ctypes.data, cn, en, buf, len(buf)))
+            assert continue_n == n
+        out.append(buf.value.decode())
+    return out
+
+
+def load_overlaps(lines, cur_id_of, ext_id_of) -> np.ndarray:
+    """OverlapRange::load (overlap.h:238-251): ids through the caller's recordByName lookups."""
+    L = load_library()
+    recs = np.zeros(len(lines), REC_DTYPE)
+    offs = [C.c_uint32() for _ in range(4)]
+    for i, line in enumerate(lines):
+        raw = line.encode()
+        rc = L.fg_overlap_load(raw, recs[i:i + 1].ctypes.data, *[C.byref(o) for o in offs])
+        if rc != 0:
+            raise FlyeGpuError(rc, f"malformed overlap line {i}")
+        recs["cur_id"][i] = cur_id_of(raw[offs[0].value:offs[0].value + offs[1].value].decode())
+        recs["ext_id"][i] = ext_id_of(raw[offs[2].value:offs[2].value + offs[3].value].decode())
+    return recs
+
+
+def fasta_text(rs, names) -> str:
+    """SequenceContainer::writeFasta(records, file, onlyPositiveStrand = true) (sequence_container.cpp:330-357)."""
+    L = load_library()
+    parts = []
+    for i in range(rs.n):
+        w = np.ascontiguousarray(rs.words[int(rs.word_off[i]):int(rs.word_off[i + 1])])
+        n = int(rs.length[i])
+        cap = n + n // 80 + len(names[i]) + 8
+        buf = C.create_string_buffer(cap)
+        got = L.fg_fasta_record(names[i].encode(), w.ctypes.data, n, buf, cap)
+        assert 0 <= got <= cap
+        parts.append(buf.raw[:got].decode())
+    return "".join(parts)
 
 
 def complement(recs: np.ndarray) -> np.ndarray:

@@ -99,6 +99,27 @@ struct fgb_stats {
 };
 void fgb_get_stats(fgb_container* c, struct fgb_stats* out);
 
+/* ---- on-disk text forms: what a stage boundary writes and reads --------------
+ * OverlapRange::dump / load (src/sequence/overlap.h:227-251): one overlap as
+ *   "<curName> <curBegin> <curEnd> <curLen> <extName> <extBegin> <extEnd> <extLen> -1 -1 <score> <div>"
+ * with the names SequenceContainer::seqName gives ('+' / '-' + FASTA header,
+ * sequence_container.cpp:62, :75) and the divergence in operator<<(float)'s default form (%g).
+ * fg_overlap_dump writes the line (no newline) and returns its length, or the length needed when it
+ * does not fit cap.  fg_overlap_load parses one: ids are the caller's business (recordByName), the
+ * names come back as offsets into the line; returns FG_OK or FG_ERR_ARG on a malformed line. */
+int64_t fg_overlap_dump(const struct fg_overlap_rec* rec, const char* cur_name, const char* ext_name,
+                        char* buf, uint64_t cap);
+int fg_overlap_load(const char* line, struct fg_overlap_rec* rec, uint32_t* cur_name_off, uint32_t* cur_name_len,
+                    uint32_t* ext_name_off, uint32_t* ext_name_len);
+/* One record of ReadAligner::storeAlignments (src/repeat_graph/read_aligner.cpp:321-339):
+ * "\tAln\t<edgeId>\t" + the dump line; chains are introduced by a "Chain" line the caller writes. */
+int64_t fg_alignment_dump(int64_t edge_id, const struct fg_overlap_rec* rec, const char* read_name,
+                          const char* edge_name, char* buf, uint64_t cap);
+/* SequenceContainer::writeFasta's form of one record (sequence_container.cpp:330-357): ">" + name and
+ * the sequence in slices of 80, from DnaSequence packing (32 nt per uint64).  Returns the length
+ * written / needed as above. */
+int64_t fg_fasta_record(const char* name, const uint64_t* words, int32_t len, char* buf, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,7 +52,7 @@ static uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 int main(int argc, char** argv)
 {
-	std::string reads, queriesFile, params, config, indexOut, ovlpOut, divMode = "none";
+	std::string reads, queriesFile, params, config, indexOut, ovlpOut, dumpOut, fastaOut, divMode = "none";
 	int onlyMax = 1, maxOverhang = -1, nuclAln = -1, keepAln = 0, partitionBad = 0;
 	float maxDiv = 1.0f;
 	int threads = 1, minReadLen = 0, maxOverlaps = 0, forceLocal = 0;
@@ -74,6 +74,8 @@ int main(int argc, char** argv)
 		else if (a == "--div-mode") divMode = next();
 		else if (a == "--index-out") indexOut = next();
 		else if (a == "--ovlp-out") ovlpOut = next();
+		else if (a == "--dump-out") dumpOut = next();	// every overlap through the reference's OverlapRange::dump
+		else if (a == "--fasta-out") fastaOut = next();	// the loaded reads through SequenceContainer::writeFasta
 		else if (a == "--query-limit") queryLimit = atol(next().c_str());
 		else if (a == "--rc-queries") rcQueries = true;
 		else if (a == "--find-all") findAll = true;	// OverlapContainer::findAllOverlaps (overlap.cpp:625-665)
@@ -276,6 +278,15 @@ int main(int argc, char** argv)
 		fclose(f);
 	}
 	else for (auto& vec : results) total += vec.size();
+	if (!dumpOut.empty())
+	{
+		// the on-disk forms (overlap.h:227-236; read_aligner.cpp:321-339 puts "\tAln\t<edgeId>\t" in front)
+		std::ofstream os(dumpOut);
+		for (auto& vec : results)
+			for (auto& o : vec) { o.dump(os, qc, readsContainer); os << "\n"; }
+	}
+	if (!fastaOut.empty())
+		SequenceContainer::writeFasta(readsContainer.iterSeqs(), fastaOut, /*only positive strand*/ true);
 
 	auto sec = [](clk::time_point a, clk::time_point b)
 		{ return std::chrono::duration<double>(b - a).count(); };

@@ -303,10 +303,21 @@ def test_batching_container_under_threads(built):
     work = [rng.permutation(np.concatenate([allq, allq[: rs.n]])) for _ in range(16)]
     errors = []
 
+    bad_id = 2 * rs.n + 6
+
     def worker(t):
         try:
             for j, rid in enumerate(work[t]):
                 rid = int(rid)
+                if t == 3 and j % 50 == 0:
+                    # an id outside the container is this caller's error alone: the other threads' requests that
+                    # share its batch are answered normally and nothing is cached for it
+                    for call in (lambda: oc.lazySeqOverlaps(bad_id), lambda: oc.quickSeqOverlaps(bad_id, 5, True)):
+                        try:
+                            call()
+                            raise AssertionError("bad id accepted")
+                        except gpu.FlyeGpuError as e:
+                            assert e.code == -3
                 got = oc.lazySeqOverlaps(rid)
                 want = direct.of(rid & ~1)
                 if rid & 1:
