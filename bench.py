@@ -108,7 +108,12 @@ def main():
     ctx.set_reads(rs)
     t_upload = time.time() - t0
     vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
-    st = vi.build(cfg)
+    if world > 1:
+        # index build sharded by key range over the ranks: sums all-reduce + all-gather of the CSR pieces
+        # (RCCL over xGMI with the nccl backend), every rank then holds the whole index (flye_amd/dist.py)
+        st = dist.build_index_sharded(vi, cfg, rank, world, on_device=(backend == "nccl"))
+    else:
+        st = vi.build(cfg)
     # --min-ovlp of the pipeline driver (N90 rule) only filters reads by length (main_assemble.cpp:183, done in
     # workloads.ecoli_pb50) and feeds Extender; the DETECTOR always runs with minimumOverlap = 1000
     # (main_assemble.cpp:174 overrides the parameter before the detector is built at :229-238)
@@ -193,7 +198,8 @@ def main():
                        "genome_bp": int(4_640_000 * scale), "reads": rs.n, "read_bp": rs.total_bases,
                        "queries_per_rank": int(len(queries)), "min_overlap": det_min_ovlp, "min_read_len": min_ovlp,
                        "kmer": int(cfg["kmer_size"]),
-                       "sharding": f"reads by id over {world} rank(s), index replicated, no collective"},
+                       "sharding": f"queries: reads by id over {world} rank(s), no data-path collective; index: built sharded by "
+                                   f"key range + all-gather, then resident on every rank"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_note,
@@ -202,7 +208,10 @@ def main():
                      "overlaps": int(len(res.recs)), "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
                      "kernel_ms_per_step": {k: round(v[0] / args.steps * 1e3, 3) for k, v in
                                             sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
-                     "index_build_s": round(st["build_seconds"], 3), "read_gen_s": round(t_gen, 2),
+                     "index_build_s": round(st["build_seconds"], 3),
+                     "index_build_collectives": ({"bytes": int(st["collective_bytes"]), "allgather_s": round(st["allgather_s"], 4),
+                                                  "piece_of_rank0": list(st["piece"])} if world > 1 else None),
+                     "read_gen_s": round(t_gen, 2),
                      "upload_s": round(t_upload, 3), "index_entries": int(st["index_entries"])},
         }
         if world == 1 and not args.no_cpu:

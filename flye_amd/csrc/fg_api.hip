@@ -220,6 +220,80 @@ int fg_build_index_minimizers(fg_ctx* c, int32_t min_coverage, int32_t window, f
 	});
 }
 
+int fg_index_begin_solid(fg_ctx* c, int32_t min_freq, float select_rate, int32_t tandem_freq, float repeat_rate,
+						 float sample_rate_init, uint64_t* hist)
+{
+	if (!c) return FG_ERR_ARG;
+	if (!(select_rate >= 0.0f && select_rate < 1.0f)) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgIndexBeginSolid(c, min_freq, select_rate, tandem_freq, repeat_rate, sample_rate_init, hist);
+	});
+}
+
+int fg_index_begin_minimizers(fg_ctx* c, int32_t min_coverage, int32_t window, float repeat_rate, uint64_t* hist)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgIndexBeginMinimizers(c, min_coverage, window, repeat_rate, hist);
+	});
+}
+
+int fg_index_build_range(fg_ctx* c, uint32_t bin_lo, uint32_t bin_hi, uint64_t* sums)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		unsigned long long s2[2];
+		fgIndexBuildRange(c, bin_lo, bin_hi, s2);
+		if (sums) { sums[0] = s2[0]; sums[1] = s2[1]; }
+	});
+}
+
+int fg_index_finish(fg_ctx* c, const uint64_t* total_sums, struct fg_index_stats* out)
+{
+	if (!c || !out) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		unsigned long long s2[2] = {0, 0};
+		if (total_sums) { s2[0] = total_sums[0]; s2[1] = total_sums[1]; }
+		fgIndexFinish(c, total_sums ? s2 : nullptr, out);
+	});
+}
+
+int fg_import_index(fg_ctx* c, uint64_t n_keys, const uint64_t* keys, const uint64_t* key_off, uint64_t n_entries,
+					const uint64_t* entries, uint64_t n_repetitive, const uint64_t* repetitive_keys, float sample_rate,
+					int on_device)
+{
+	if (!c || !key_off || (n_keys && !keys) || (n_entries && !entries) || (n_repetitive && !repetitive_keys)) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgImportIndex(c, n_keys, keys, key_off, n_entries, entries, n_repetitive, repetitive_keys, sample_rate, on_device);
+	});
+}
+
+int fg_index_device_arrays(fg_ctx* c, uint64_t* n_keys, uint64_t* n_entries, uint64_t* n_repetitive,
+						   const uint64_t** keys, const uint64_t** key_off, const uint64_t** entries,
+						   const uint64_t** repetitive_keys)
+{
+	if (!c) return FG_ERR_ARG;
+	if (!c->indexBuilt) return FG_ERR_STATE;
+	if (n_keys) *n_keys = c->nKeys;
+	if (n_entries) *n_entries = c->nEntries;
+	if (n_repetitive) *n_repetitive = c->nRep;
+	if (keys) *keys = c->dKeys.p;
+	if (key_off) *key_off = c->dKeyOff.p;
+	if (entries) *entries = c->dEntries.p;
+	if (repetitive_keys) *repetitive_keys = c->dRepKeys.p;
+	return FG_OK;
+}
+
 int fg_clear_index(fg_ctx* c)
 {
 	if (!c) return FG_ERR_ARG;
@@ -227,6 +301,7 @@ int fg_clear_index(fg_ctx* c)
 	{
 		HIP_CHECK(hipSetDevice(c->device));
 		c->indexBuilt = false;
+		c->indexBuild.reset();
 		c->dKeys.release(); c->dKeyOff.release(); c->dEntries.release(); c->dRepKeys.release();
 		c->dTable.release(); c->dIndexedBits.release();
 		c->nKeys = c->nEntries = c->nRep = c->tableSlots = 0;

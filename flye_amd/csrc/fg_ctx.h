@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 
 #include "../../include/flye_gpu.h"
 
@@ -178,6 +179,8 @@ struct fg_ctx {
 	DevBuf<u64> dRepKeys;	// ascending
 	DevBuf<ulonglong2> dTable;	// {key, off<<24 | cnt}
 	DevBuf<u32> dIndexedBits;	// one bit per forward k-mer position: contributes an entry
+
+	std::shared_ptr<void> indexBuild;	// state between the steps of an index build (fg_index.hip)
 
 	// overlap-stage scratch (grow-only)
 	DevBuf<u32> dQuery;			// query record indices
@@ -390,6 +393,15 @@ struct PrimRec {
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, fg_index_stats* st);
 void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st);
+// the same in steps (sharded builds): begin -> ranges of key bins -> finish; fg_index.hip
+void fgIndexBeginSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, u64* histOut);
+void fgIndexBeginMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, u64* histOut);
+void fgIndexBuildRange(fg_ctx* c, u32 binLo, u32 binHi, unsigned long long* sumsOut);
+void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stats* st);
+void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags);
+void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64 nEnt, const u64* entries, u64 nRep,
+				   const u64* repKeys, float sampleRate, int onDevice);
 // keyMode: 0 = 32-bit keys, 1 = packed 64-bit records (PK), 2 = 64-bit keys + values
 void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits);

@@ -306,14 +306,23 @@ __global__ void k_minimizers(const u64* __restrict__ words, const u64* __restric
 // flipped, position mirrored)
 __global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wordOff,
 					   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-					   const uint8_t* __restrict__ flags, int posBits, u64* __restrict__ ecanon,
-					   u64* __restrict__ evalue, unsigned long long* __restrict__ cursor)
+					   const uint8_t* __restrict__ flags, int posBits, u64 keyLo, u64 keyHi /* canonical k-mers in [lo, hi) */,
+					   u64* __restrict__ ecanon, u64* __restrict__ evalue, unsigned long long* __restrict__ cursor)
 {
 	const u32 r = blockIdx.x;
 	const i32 L = len[r];
 	const i32 nk = L - k;
 	const u64* w = words + wordOff[r];
 	const uint8_t* fl = flags + kmerOff[r];
+	const bool all = keyLo == 0 && keyHi == ~0ULL;
+	auto inSlice = [&](i32 p) -> bool
+	{
+		if (all) return true;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 c = fw < rv ? fw : rv;
+		return c >= keyLo && c < keyHi;
+	};
 	// ONE cursor atomic per read: same-address atomics serialise at ~11 ns each, and one per
 	// wave and step (what the compiler's aggregation of a per-element atomicAdd gives) was 3.4 M of
 	// them = 39 of the build's 85 ms.  The emission order is irrelevant (radix sort follows).
@@ -321,7 +330,7 @@ __global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wo
 	__shared__ u64 shBase;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	u32 mine = 0;
-	for (i32 p = threadIdx.x; p < nk; p += WG) mine += fl[p] ? 1u : 0u;
+	for (i32 p = threadIdx.x; p < nk; p += WG) mine += (fl[p] && inSlice(p)) ? 1u : 0u;
 	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
 	if (lane == 0) shw[wv] = mine;
 	__syncthreads();
@@ -336,7 +345,7 @@ __global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wo
 	for (i32 p0 = 0; p0 < nk; p0 += WG)
 	{
 		const i32 p = p0 + (i32)threadIdx.x;
-		const bool take = p < nk && fl[p];
+		const bool take = p < nk && fl[p] && inSlice(p);
 		const u64 m = __ballot(take);
 		__syncthreads();
 		if (lane == 0) shw[wv] = (u32)__popcll(m);
@@ -354,6 +363,32 @@ __global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wo
 		}
 		base += tot;
 	}
+}
+
+// accepted positions per key bin (bin = canonical k-mer >> binShift): what the slicing of the build --
+// by memory on one GPU, by rank on several -- balances on
+#define FG_INDEX_BINS 4096
+__global__ void k_bin_hist(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+						   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+						   const uint8_t* __restrict__ flags, int binShift, unsigned long long* __restrict__ hist)
+{
+	__shared__ u32 sh[FG_INDEX_BINS];
+	for (int i = threadIdx.x; i < FG_INDEX_BINS; i += WG) sh[i] = 0;
+	__syncthreads();
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const uint8_t* fl = flags + kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+		if (fl[p])
+		{
+			u64 fw, rv;
+			fg_kmer_pair(w, p, k, fw, rv);
+			atomicAdd(&sh[(fw < rv ? fw : rv) >> binShift], 1u);
+		}
+	__syncthreads();
+	for (int i = threadIdx.x; i < FG_INDEX_BINS; i += WG)
+		if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
 }
 
 __global__ void k_heads(const u64* __restrict__ c, u64 n, u32* __restrict__ flag)
@@ -406,27 +441,51 @@ __global__ void k_classify(const u64* __restrict__ ukeys, const u64* __restrict_
 	if (!rep && cap + 1 > (u64)(32 * 1024 * 1024 / 5)) *err = 1;
 }
 
+// totals of one part under the final repFreq: repetitive keys, kept keys, entries (same rules as k_classify)
+__global__ void k_classify_count(const u64* __restrict__ ukeys, const u64* __restrict__ kstart, u64 nKeys, u64 repFreq,
+								 const u32* __restrict__ counts, unsigned long long* __restrict__ out /* rep, keep, entries */)
+{
+	__shared__ u64 sh[WG / 64];
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	u64 rep = 0, keep = 0, ent = 0;
+	if (j < nKeys)
+	{
+		const u64 cap = kstart[j + 1] - kstart[j];
+		const bool r = cap > repFreq;
+		bool filled = !r;
+		if (filled && counts) filled = (u64)counts[ukeys[j]] <= repFreq;
+		rep = r; keep = !r; ent = filled ? cap : 0;
+	}
+	u64 t = block_sum(rep, sh);
+	if (threadIdx.x == 0 && t) atomicAdd(&out[0], (unsigned long long)t);
+	t = block_sum(keep, sh);
+	if (threadIdx.x == 0 && t) atomicAdd(&out[1], (unsigned long long)t);
+	t = block_sum(ent, sh);
+	if (threadIdx.x == 0 && t) atomicAdd(&out[2], (unsigned long long)t);
+}
+
+// one part's keys / offsets / repetitive keys into the final arrays, behind what earlier parts wrote
 __global__ void k_finalize(const u64* __restrict__ ukeys, u64 nKeys, const u32* __restrict__ isRep,
 						   const u32* __restrict__ repIdx, const u32* __restrict__ keepIdx,
-						   const u64* __restrict__ off, u64* __restrict__ keys, u64* __restrict__ keyOff,
-						   u64* __restrict__ repKeys)
+						   const u64* __restrict__ off, u64 keepBase, u64 repBase, u64 entBase,
+						   u64* __restrict__ keys, u64* __restrict__ keyOff, u64* __restrict__ repKeys)
 {
 	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
 	if (j >= nKeys) return;
-	if (isRep[j]) repKeys[repIdx[j]] = ukeys[j];
-	else { keys[keepIdx[j]] = ukeys[j]; keyOff[keepIdx[j]] = off[j]; }
+	if (isRep[j]) repKeys[repBase + repIdx[j]] = ukeys[j];
+	else { keys[keepBase + keepIdx[j]] = ukeys[j]; keyOff[keepBase + keepIdx[j]] = entBase + off[j]; }
 }
 
 __global__ void k_entries(const u64* __restrict__ evalue, u64 n, const u32* __restrict__ inc,
 						  const u64* __restrict__ kstart, const u64* __restrict__ size,
-						  const u64* __restrict__ off, int posBits, u64* __restrict__ entries)
+						  const u64* __restrict__ off, int posBits, u64 entBase, u64* __restrict__ entries)
 {
 	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
 	if (i >= n) return;
 	const u32 j = inc[i] - 1;
 	if (size[j] == 0) return;
 	const u64 v = evalue[i];
-	entries[off[j] + (i - kstart[j])] = ((v >> posBits) << 32) | (v & ((1ULL << posBits) - 1));
+	entries[entBase + off[j] + (i - kstart[j])] = ((v >> posBits) << 32) | (v & ((1ULL << posBits) - 1));
 }
 
 __global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restrict__ keyOff, u64 nKeys,
@@ -458,22 +517,35 @@ __global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restri
 // without searching the list)
 __global__ void k_indexed_bits(const u64* __restrict__ words, const u64* __restrict__ wordOff,
 							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-							   const uint8_t* __restrict__ flags, const ulonglong2* __restrict__ table,
-							   u64 mask, u32* __restrict__ bits)
+							   const uint8_t* __restrict__ flags /* the build's selection, or null */,
+							   const ulonglong2* __restrict__ table, u64 mask, const u64* __restrict__ entries,
+							   u32* __restrict__ bits)
 {
 	const u32 r = blockIdx.x;
-	const i32 nk = len[r] - k;
+	const i32 L = len[r];
+	const i32 nk = L - k;
 	const u64* w = words + wordOff[r];
-	const uint8_t* fl = flags + kmerOff[r];
+	const uint8_t* fl = flags ? flags + kmerOff[r] : nullptr;
 	const u64 base = kmerOff[r];
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
-		if (!fl[p]) continue;
+		if (fl && !fl[p]) continue;
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
-		const u64 v = fg_probe(table, mask, fw < rv ? fw : rv);
-		if (v != 0 && (v & FG_CNT_MASK) != FG_CNT_REPETITIVE)
-			atomicOr(&bits[(base + p) >> 5], 1u << ((base + p) & 31));
+		const bool flip = rv < fw;
+		const u64 v = fg_probe(table, mask, flip ? rv : fw);
+		if (v == 0 || (v & FG_CNT_MASK) == FG_CNT_REPETITIVE) continue;
+		if (!fl)
+		{
+			// an imported index carries no selection flags: a position owns an entry iff its own
+			// (record, position) is in the k-mer's list (ascending, vertex_index.cpp:108-114)
+			const u64 own = ((u64)(2 * r + (flip ? 1u : 0u)) << 32) | (u32)(flip ? L - p - k : p);
+			const u64* e = entries + ((v >> FG_CNT_BITS) & ((1ULL << 38) - 1));
+			u32 lo = 0, hi = (u32)(v & FG_CNT_MASK);
+			while (lo < hi) { const u32 m = (lo + hi) >> 1; if (e[m] < own) lo = m + 1; else hi = m; }
+			if (lo >= (u32)(v & FG_CNT_MASK) || e[lo] != own) continue;
+		}
+		atomicOr(&bits[(base + p) >> 5], 1u << ((base + p) & 31));
 	}
 }
 
@@ -521,107 +593,275 @@ T fetch(fg_ctx* c, const T* dptr)
 int bitsFor(u64 v) { int b = 1; while ((1ULL << b) <= v && b < 63) ++b; return b; }
 unsigned gridFor(u64 n) { return (unsigned)((n + WG - 1) / WG); }
 
-// common tail of both build modes: (canon, value) pairs -> CSR + probe table
-void finishIndex(fg_ctx* c, Prim& prim, DevBuf<u64>& ecanon, DevBuf<u64>& evalue, u64 E, int posBits,
-				 i32 minCoverage, float repeatRate, const u32* counts, const uint8_t* flags,
-				 fg_index_stats* st)
+
+// ---- the build in three steps ------------------------------------------------------------------
+//   begin        k-mer selection over ALL reads (solid: exact counts + per-read frequency threshold +
+//                tandem filter, vertex_index.cpp:19-125; minimizers: kmer.h:206-262) -> one flag per
+//                k-mer position, and the number of accepted positions per key bin
+//   build range  for the keys of bins [lo, hi): emit (canonical k-mer, position) pairs, two stable
+//                LSD radix sorts (position, then k-mer), run-length encode -> one PART (unique keys,
+//                list starts, sorted positions) + its share of filterFrequentKmers' sums
+//                (vertex_index.cpp:175-184).  Ranges wider than the memory budget are cut.
+//   finish       with the sums over ALL keys: repetitive frequency, classification, CSR arrays in key
+//                order, probe table, indexed bits.
+// One GPU runs begin, the whole key space, finish.  Several GPUs each run begin (replicated: the
+// selection needs every read), the range their rank owns (flye_amd/dist.py balances the ranges on
+// the bin histogram), exchange the two sums, finish their piece, all-gather the pieces and import the
+// concatenation (fgImportIndex) -- SURVEY.md §8(e).
+struct IndexPart {
+	DevBuf<u64> ukeys, kstart, evalue;
+	DevBuf<u32> inc;
+	u64 nKeys = 0, E = 0;
+};
+
+struct IndexBuild {
+	bool solid = false;
+	DevBuf<u32> counts;			// solid mode: exact count of every possible k-mer
+	DevBuf<uint8_t> flags;		// 1 = this k-mer position contributes an entry
+	int posBits = 0, binShift = 0;
+	i32 minCoverage = 0;
+	float repeatRate = 0, sampleRateInit = 1.0f;
+	u64 totalDistinct = 0;
+	std::vector<u64> hist;		// accepted positions per bin
+	std::vector<std::unique_ptr<IndexPart>> parts;	// ascending key ranges
+	unsigned long long sums[2] = {0, 0};
+	double seconds = 0;
+};
+
+struct BuildClock {
+	fg_ctx* c; hipEvent_t a, b;
+	BuildClock(fg_ctx* c_) : c(c_), a(c_->timer.get()), b(nullptr)
+	{
+		try { b = c_->timer.get(); } catch (...) { c_->timer.pool.push_back(a); throw; }
+		HIP_CHECK(hipEventRecord(a, c->stream));
+	}
+	double stop()
+	{
+		HIP_CHECK(hipEventRecord(b, c->stream));
+		HIP_CHECK(hipEventSynchronize(b));
+		float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+		return ms * 1e-3;
+	}
+	~BuildClock() { c->timer.pool.push_back(a); c->timer.pool.push_back(b); }
+};
+
+IndexBuild* buildState(fg_ctx* c)
+{
+	if (!c->indexBuild) throw FgError{FG_ERR_STATE, "no index build in progress (call the begin step first)"};
+	return (IndexBuild*)c->indexBuild.get();
+}
+
+void clearIndex(fg_ctx* c)
+{
+	c->indexBuilt = false;
+	c->dKeys.release(); c->dKeyOff.release(); c->dEntries.release(); c->dRepKeys.release();
+	c->dTable.release(); c->dIndexedBits.release();
+	c->nKeys = c->nEntries = c->nRep = c->tableSlots = 0;
+}
+
+void binHistogram(fg_ctx* c, IndexBuild* B, u64* histOut)
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
+	B->binShift = std::max(0, 2 * k - 12);
+	DevBuf<unsigned long long> dh;
+	dh.alloc(FG_INDEX_BINS);
+	HIP_CHECK(hipMemsetAsync(dh.p, 0, FG_INDEX_BINS * 8, s));
+	if (c->nReads)
+	{
+		ScopedK t(c->timer, "k_bin_hist");
+		hipLaunchKernelGGL(k_bin_hist, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+						   B->flags.p, B->binShift, dh.p);
+	}
+	B->hist.assign(FG_INDEX_BINS, 0);
+	HIP_CHECK(hipMemcpyAsync(B->hist.data(), dh.p, FG_INDEX_BINS * 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (histOut) memcpy(histOut, B->hist.data(), FG_INDEX_BINS * 8);
+}
+
+// one slice of keys -> one part
+void buildPart(fg_ctx* c, IndexBuild* B, Prim& prim, u32 binLo, u32 binHi, u64 E)
+{
+	if (E == 0) return;
+	hipStream_t s = c->stream;
+	const int k = c->k;
 	const u32 n = c->nReads;
-	DevBuf<u64> ecanon2, evalue2;
+	const u64 keyLo = (u64)binLo << B->binShift;
+	const u64 keyHi = binHi >= FG_INDEX_BINS ? ~0ULL : ((u64)binHi << B->binShift);
+	std::unique_ptr<IndexPart> part(new IndexPart);
+	DevBuf<u64> ecanon, ecanon2, evalue2;
+	DevBuf<unsigned long long> cursor;
+	ecanon.alloc(E); part->evalue.alloc(E); cursor.alloc(1);
+	HIP_CHECK(hipMemsetAsync(cursor.p, 0, 8, s));
+	{
+		ScopedK t(c->timer, "k_emit");
+		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->flags.p,
+						   B->posBits, (binLo == 0 && binHi >= FG_INDEX_BINS) ? 0ULL : keyLo,
+						   (binLo == 0 && binHi >= FG_INDEX_BINS) ? ~0ULL : keyHi, ecanon.p, part->evalue.p, cursor.p);
+	}
+	if (fetch(c, cursor.p) != E) throw FgError{FG_ERR_HIP, "internal: slice emission does not match the bin histogram"};
 	ecanon2.alloc(E); evalue2.alloc(E);
-	const int valBits = posBits + bitsFor(2ULL * n);
+	const int valBits = B->posBits + bitsFor(2ULL * n);
 	{
 		ScopedK t(c->timer, "radix_sort_pairs(rocprim)");
-		prim.sortPairs(evalue.p, evalue2.p, ecanon.p, ecanon2.p, E, valBits);
-		prim.sortPairs(ecanon2.p, ecanon.p, evalue2.p, evalue.p, E, 2 * k);
+		prim.sortPairs(part->evalue.p, evalue2.p, ecanon.p, ecanon2.p, E, valBits);
+		prim.sortPairs(ecanon2.p, ecanon.p, evalue2.p, part->evalue.p, E, 2 * k);
 	}
 	ecanon2.release(); evalue2.release();
-
 	// run-length encode the sorted k-mers
-	DevBuf<u32> flag, inc;
-	flag.alloc(E); inc.alloc(E);
-	u64 nKeys = 0;
-	if (E)
-	{
-		{ ScopedK t(c->timer, "k_heads"); hipLaunchKernelGGL(k_heads, gridFor(E), WG, 0, s, ecanon.p, E, flag.p); }
-		{ ScopedK t(c->timer, "scan(rocprim)"); prim.incScan(flag.p, inc.p, E); }
-		nKeys = fetch(c, inc.p + (E - 1));
-	}
-	DevBuf<u64> ukeys, kstart;
-	ukeys.alloc(nKeys); kstart.alloc(nKeys + 1);
-	if (E)
+	DevBuf<u32> flag;
+	flag.alloc(E); part->inc.alloc(E);
+	{ ScopedK t(c->timer, "k_heads"); hipLaunchKernelGGL(k_heads, gridFor(E), WG, 0, s, ecanon.p, E, flag.p); }
+	{ ScopedK t(c->timer, "scan(rocprim)"); prim.incScan(flag.p, part->inc.p, E); }
+	const u64 nKeys = fetch(c, part->inc.p + (E - 1));
+	part->ukeys.alloc(nKeys); part->kstart.alloc(nKeys + 1);
 	{
 		ScopedK t(c->timer, "k_keys");
-		hipLaunchKernelGGL(k_keys, gridFor(E), WG, 0, s, ecanon.p, E, flag.p, inc.p, ukeys.p, kstart.p);
+		hipLaunchKernelGGL(k_keys, gridFor(E), WG, 0, s, ecanon.p, E, flag.p, part->inc.p, part->ukeys.p, part->kstart.p);
 	}
-	HIP_CHECK(hipMemcpyAsync(kstart.p + nKeys, &E, 8, hipMemcpyHostToDevice, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	flag.release();
-
-	// filterFrequentKmers: two integer sums on the device, the two float
-	// operations on the host exactly as vertex_index.cpp:185-186 writes them
+	HIP_CHECK(hipMemcpyAsync(part->kstart.p + nKeys, &E, 8, hipMemcpyHostToDevice, s));
+	// filterFrequentKmers' two integer sums (its two float operations run on the host in the finish step)
 	DevBuf<unsigned long long> sums;
 	sums.alloc(2);
 	HIP_CHECK(hipMemsetAsync(sums.p, 0, 16, s));
-	if (nKeys)
 	{
 		ScopedK t(c->timer, "k_capstats");
-		hipLaunchKernelGGL(k_capstats, gridFor(nKeys), WG, 0, s, kstart.p, nKeys, minCoverage, sums.p);
+		hipLaunchKernelGGL(k_capstats, gridFor(nKeys), WG, 0, s, part->kstart.p, nKeys, B->minCoverage, sums.p);
 	}
 	unsigned long long hs[2];
 	HIP_CHECK(hipMemcpyAsync(hs, sums.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	size_t totalKmers = hs[0], uniqueKmers = hs[1];
+	B->sums[0] += hs[0]; B->sums[1] += hs[1];
+	part->nKeys = nKeys; part->E = E;
+	B->parts.push_back(std::move(part));
+}
+
+} // namespace
+
+void fgIndexBuildRange(fg_ctx* c, u32 binLo, u32 binHi, unsigned long long* sumsOut)
+{
+	IndexBuild* B = buildState(c);
+	if (binLo > binHi || binHi > FG_INDEX_BINS) throw FgError{FG_ERR_ARG, "bin range outside [0, 4096]"};
+	BuildClock clock(c);
+	Prim prim{c};
+	// slices of at most `budget` entries (sort scratch = 4 x 8 bytes per entry of the slice)
+	const u64 budget = getenv("FG_INDEX_SLICE_ENTRIES") ? strtoull(getenv("FG_INDEX_SLICE_ENTRIES"), nullptr, 10) : (768ULL << 20);
+	u32 lo = binLo;
+	while (lo < binHi)
+	{
+		u32 hi = lo;
+		u64 e = 0;
+		while (hi < binHi && (hi == lo || e + B->hist[hi] <= budget)) { e += B->hist[hi]; ++hi; }
+		buildPart(c, B, prim, lo, hi, e);
+		lo = hi;
+	}
+	if (sumsOut) { sumsOut[0] = B->sums[0]; sumsOut[1] = B->sums[1]; }
+	B->seconds += clock.stop();
+}
+
+// the index over what the parts hold: keys ascending, lists ascending (record, position)
+void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stats* st)
+{
+	IndexBuild* B = buildState(c);
+	hipStream_t s = c->stream;
+	BuildClock clock(c);
+	Prim prim{c};
+	memset(st, 0, sizeof(*st));
+	const unsigned long long t0 = totalSums ? totalSums[0] : B->sums[0], t1 = totalSums ? totalSums[1] : B->sums[1];
+	// vertex_index.cpp:185-186, the two float operations exactly as written there
+	size_t totalKmers = t0, uniqueKmers = t1;
 	float meanFrequency = (float)totalKmers / (uniqueKmers + 1);
-	size_t repFreq = repeatRate * meanFrequency;
+	size_t repFreq = B->repeatRate * meanFrequency;
 	st->mean_frequency = meanFrequency;
 	st->repetitive_frequency = repFreq;
+	st->total_kmers = B->totalDistinct;
 
-	DevBuf<u32> isRep, keep, repIdx, keepIdx, err;
-	DevBuf<u64> size, off;
-	isRep.alloc(nKeys + 1); keep.alloc(nKeys + 1); repIdx.alloc(nKeys + 1); keepIdx.alloc(nKeys + 1);
-	size.alloc(nKeys + 1); off.alloc(nKeys + 1); err.alloc(1);
-	HIP_CHECK(hipMemsetAsync(err.p, 0, 4, s));
-	// one extra zero element so that the exclusive scans also yield the totals
-	HIP_CHECK(hipMemsetAsync(isRep.p + nKeys, 0, 4, s));
-	HIP_CHECK(hipMemsetAsync(keep.p + nKeys, 0, 4, s));
-	HIP_CHECK(hipMemsetAsync(size.p + nKeys, 0, 8, s));
-	if (nKeys)
+	// totals first (the final arrays are allocated once), then part by part behind one another
+	DevBuf<unsigned long long> tot;
+	tot.alloc(3);
+	HIP_CHECK(hipMemsetAsync(tot.p, 0, 24, s));
+	for (auto& p : B->parts)
 	{
 		ScopedK t(c->timer, "k_classify");
-		hipLaunchKernelGGL(k_classify, gridFor(nKeys), WG, 0, s, ukeys.p, kstart.p, nKeys, (u64)repFreq, counts,
-						   isRep.p, keep.p, size.p, err.p);
+		hipLaunchKernelGGL(k_classify_count, gridFor(p->nKeys), WG, 0, s, p->ukeys.p, p->kstart.p, p->nKeys, (u64)repFreq,
+						   B->solid ? B->counts.p : (const u32*)nullptr, tot.p);
 	}
-	{
-		ScopedK t(c->timer, "scan(rocprim)");
-		prim.excScan(isRep.p, repIdx.p, nKeys + 1);
-		prim.excScan(keep.p, keepIdx.p, nKeys + 1);
-		prim.excScan(size.p, off.p, nKeys + 1);
-	}
-	const u64 nRep = fetch(c, repIdx.p + nKeys);
-	const u64 nKeep = fetch(c, keepIdx.p + nKeys);
-	const u64 nEnt = fetch(c, off.p + nKeys);
-	if (fetch(c, err.p)) throw FgError{FG_ERR_KMER_TOO_FREQUENT, "k-mer is too frequent"};
-
+	unsigned long long ht[3];
+	HIP_CHECK(hipMemcpyAsync(ht, tot.p, 24, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	const u64 nRep = ht[0], nKeep = ht[1], nEnt = ht[2];
+	clearIndex(c);
 	c->dKeys.alloc(nKeep); c->dKeyOff.alloc(nKeep + 1); c->dEntries.alloc(nEnt); c->dRepKeys.alloc(nRep);
-	if (nKeys)
+	u64 keepBase = 0, repBase = 0, entBase = 0;
+	DevBuf<u32> err;
+	err.alloc(1);
+	HIP_CHECK(hipMemsetAsync(err.p, 0, 4, s));
+	for (auto& p : B->parts)
 	{
-		ScopedK t(c->timer, "k_finalize");
-		hipLaunchKernelGGL(k_finalize, gridFor(nKeys), WG, 0, s, ukeys.p, nKeys, isRep.p, repIdx.p, keepIdx.p,
-						   off.p, c->dKeys.p, c->dKeyOff.p, c->dRepKeys.p);
+		const u64 nKeys = p->nKeys;
+		DevBuf<u32> isRep, keep, repIdx, keepIdx;
+		DevBuf<u64> size, off;
+		isRep.alloc(nKeys + 1); keep.alloc(nKeys + 1); repIdx.alloc(nKeys + 1); keepIdx.alloc(nKeys + 1);
+		size.alloc(nKeys + 1); off.alloc(nKeys + 1);
+		// one extra zero element so that the exclusive scans also yield the totals
+		HIP_CHECK(hipMemsetAsync(isRep.p + nKeys, 0, 4, s));
+		HIP_CHECK(hipMemsetAsync(keep.p + nKeys, 0, 4, s));
+		HIP_CHECK(hipMemsetAsync(size.p + nKeys, 0, 8, s));
+		{
+			ScopedK t(c->timer, "k_classify");
+			hipLaunchKernelGGL(k_classify, gridFor(nKeys), WG, 0, s, p->ukeys.p, p->kstart.p, nKeys, (u64)repFreq,
+							   B->solid ? B->counts.p : (const u32*)nullptr, isRep.p, keep.p, size.p, err.p);
+		}
+		{
+			ScopedK t(c->timer, "scan(rocprim)");
+			prim.excScan(isRep.p, repIdx.p, nKeys + 1);
+			prim.excScan(keep.p, keepIdx.p, nKeys + 1);
+			prim.excScan(size.p, off.p, nKeys + 1);
+		}
+		const u64 pRep = fetch(c, repIdx.p + nKeys), pKeep = fetch(c, keepIdx.p + nKeys), pEnt = fetch(c, off.p + nKeys);
+		{
+			ScopedK t(c->timer, "k_finalize");
+			hipLaunchKernelGGL(k_finalize, gridFor(nKeys), WG, 0, s, p->ukeys.p, nKeys, isRep.p, repIdx.p, keepIdx.p, off.p,
+							   keepBase, repBase, entBase, c->dKeys.p, c->dKeyOff.p, c->dRepKeys.p);
+		}
+		{
+			ScopedK t(c->timer, "k_entries");
+			hipLaunchKernelGGL(k_entries, gridFor(p->E), WG, 0, s, p->evalue.p, p->E, p->inc.p, p->kstart.p, size.p, off.p,
+							   B->posBits, entBase, c->dEntries.p);
+		}
+		HIP_CHECK(hipStreamSynchronize(s));
+		keepBase += pKeep; repBase += pRep; entBase += pEnt;
+		p.reset();	// this part's memory goes before the next one's scratch comes
 	}
+	B->parts.clear();
+	if (keepBase != nKeep || repBase != nRep || entBase != nEnt) throw FgError{FG_ERR_HIP, "internal: part totals disagree"};
+	if (fetch(c, err.p)) { clearIndex(c); throw FgError{FG_ERR_KMER_TOO_FREQUENT, "k-mer is too frequent"}; }
 	HIP_CHECK(hipMemcpyAsync(c->dKeyOff.p + nKeep, &nEnt, 8, hipMemcpyHostToDevice, s));
-	if (E)
-	{
-		ScopedK t(c->timer, "k_entries");
-		hipLaunchKernelGGL(k_entries, gridFor(E), WG, 0, s, evalue.p, E, inc.p, kstart.p, size.p, off.p, posBits,
-						   c->dEntries.p);
-	}
+	B->counts.release();
 	c->nKeys = nKeep; c->nEntries = nEnt; c->nRep = nRep;
+	fgIndexLookupStructures(c, B->flags.p);
+	st->selected_kmers = nKeep;
+	st->index_entries = nEnt;
+	st->repetitive_kmers = nRep;
+	if (B->solid) c->sampleRate = B->sampleRateInit;
+	else
+	{
+		// vertex_index.cpp:480-482: _sampleRate = (float)totalLen / totalEntries
+		size_t totalLen = c->totalBases, totalEntries = c->nEntries;
+		c->sampleRate = (float)totalLen / totalEntries;
+	}
+	st->sample_rate = c->sampleRate;
+	st->build_seconds = B->seconds + clock.stop();
+	c->indexBuild.reset();
+	c->timer.collect();
+}
 
-	// probe table at load <= 0.5
+// probe table (load <= 0.5) + one "owns an entry" bit per forward k-mer position, from the CSR arrays in
+// the context.  flags: the build's per-position selection, or null (imported index: the lists are searched)
+void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags)
+{
+	hipStream_t s = c->stream;
+	const u64 nKeep = c->nKeys, nRep = c->nRep;
 	u64 slots = 1024;
 	while (slots < 2 * (nKeep + nRep)) slots <<= 1;
 	c->tableSlots = slots;
@@ -635,76 +875,54 @@ void finishIndex(fg_ctx* c, Prim& prim, DevBuf<u64>& ecanon, DevBuf<u64>& evalue
 	}
 	c->dIndexedBits.alloc((c->totalKmers + 31) / 32 + 1);
 	HIP_CHECK(hipMemsetAsync(c->dIndexedBits.p, 0, c->dIndexedBits.bytes(), s));
-	if (n)
+	if (c->nReads && c->totalKmers)
 	{
 		ScopedK t(c->timer, "k_indexed_bits");
-		hipLaunchKernelGGL(k_indexed_bits, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-						   flags, c->dTable.p, slots - 1, c->dIndexedBits.p);
+		hipLaunchKernelGGL(k_indexed_bits, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
+						   flags, c->dTable.p, slots - 1, c->dEntries.p, c->dIndexedBits.p);
 	}
 	HIP_CHECK(hipStreamSynchronize(s));
-	st->selected_kmers = nKeep;
-	st->index_entries = nEnt;
-	st->repetitive_kmers = nRep;
 	c->indexBuilt = true;
 }
 
-struct BuildClock {
-	fg_ctx* c; hipEvent_t a, b;
-	BuildClock(fg_ctx* c_) : c(c_)
-	{
-		HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-		HIP_CHECK(hipEventRecord(a, c->stream));
-	}
-	double stop()
-	{
-		HIP_CHECK(hipEventRecord(b, c->stream));
-		HIP_CHECK(hipEventSynchronize(b));
-		float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-		return ms * 1e-3;
-	}
-	~BuildClock() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
-};
-
-} // namespace
-
-void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
-					   float sampleRateInit, fg_index_stats* st)
+void fgIndexBeginSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, u64* histOut)
 {
 	if (c->k > 17) throw FgError{FG_ERR_KMER_SIZE, "Can't use flat counter for k-mer size > 17"};
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	const u32 n = c->nReads;
-	memset(st, 0, sizeof(*st));
-	c->indexBuilt = false;
-	c->timer.evs.clear();
+	clearIndex(c);
+	c->timer.reset();
+	c->indexBuild.reset();
+	std::shared_ptr<IndexBuild> B(new IndexBuild);
 	BuildClock clock(c);
-	Prim prim{c};
+	B->solid = true; B->minCoverage = minFreq; B->repeatRate = repeatRate; B->sampleRateInit = sampleRateInit;
+	B->posBits = bitsFor((u64)c->maxLen);
 
 	const u64 space = 1ULL << (2 * k);
-	DevBuf<u32> counts;
-	counts.alloc(space);
-	DevBuf<unsigned long long> scal;	// [0] distinct, [1] tandem candidates, [2] accepted, [3] cursor
+	B->counts.alloc(space);
+	DevBuf<unsigned long long> scal;	// [0] distinct, [1] tandem candidates, [2] accepted
 	scal.alloc(4);
 	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
-	{ ScopedK t(c->timer, "memset_counts"); HIP_CHECK(hipMemsetAsync(counts.p, 0, space * 4, s)); }
+	{ ScopedK t(c->timer, "memset_counts"); HIP_CHECK(hipMemsetAsync(B->counts.p, 0, space * 4, s)); }
 	DevBuf<u32> freq, thr;
-	DevBuf<uint8_t> flags;
-	freq.alloc(c->totalKmers); flags.alloc(c->totalKmers); thr.alloc(n);
+	freq.alloc(c->totalKmers); B->flags.alloc(c->totalKmers); thr.alloc(n);
 	if (n)
 	{
 		{ ScopedK t(c->timer, "k_count");
-		  hipLaunchKernelGGL(k_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, k, counts.p, scal.p); }
+		  hipLaunchKernelGGL(k_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, k, B->counts.p, scal.p); }
 		{ ScopedK t(c->timer, "k_freq");
-		  hipLaunchKernelGGL(k_freq, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, counts.p, freq.p); }
+		  hipLaunchKernelGGL(k_freq, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->counts.p, freq.p); }
 		{ ScopedK t(c->timer, "k_threshold");
 		  hipLaunchKernelGGL(k_threshold, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, selectRate, thr.p); }
 		{ ScopedK t(c->timer, "k_mark");
-		  hipLaunchKernelGGL(k_mark, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, thr.p, tandemFreq, flags.p, scal.p + 1); }
+		  hipLaunchKernelGGL(k_mark, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, thr.p, tandemFreq, B->flags.p, scal.p + 1); }
 	}
 	unsigned long long h[4];
 	HIP_CHECK(hipMemcpyAsync(h, scal.p, 32, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	st->total_kmers = h[0];
+	B->totalDistinct = h[0];
 	if (h[1] > 0)
 	{
 		u64 slots = 1024;
@@ -715,52 +933,40 @@ void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq,
 		HIP_CHECK(hipMemsetAsync(tcnt.p, 0, slots * 4, s));
 		{ ScopedK t(c->timer, "k_tandem_insert");
 		  hipLaunchKernelGGL(k_tandem_insert, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							 flags.p, tkeys.p, tcnt.p, slots - 1); }
+							 B->flags.p, tkeys.p, tcnt.p, slots - 1); }
 		{ ScopedK t(c->timer, "k_tandem_apply");
 		  hipLaunchKernelGGL(k_tandem_apply, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							 flags.p, tkeys.p, tcnt.p, slots - 1, tandemFreq); }
+							 B->flags.p, tkeys.p, tcnt.p, slots - 1, tandemFreq); }
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
 	if (n)
 	{
 		ScopedK t(c->timer, "k_accept");
-		hipLaunchKernelGGL(k_accept, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, minFreq, flags.p, scal.p + 2);
+		hipLaunchKernelGGL(k_accept, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, minFreq, B->flags.p, scal.p + 2);
 	}
-	const u64 E = fetch(c, scal.p + 2);
 	freq.release();
-	DevBuf<u64> ecanon, evalue;
-	ecanon.alloc(E); evalue.alloc(E);
-	const int posBits = bitsFor((u64)c->maxLen);
-	if (n && E)
-	{
-		ScopedK t(c->timer, "k_emit");
-		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, flags.p,
-						   posBits, ecanon.p, evalue.p, scal.p + 3);
-	}
-	finishIndex(c, prim, ecanon, evalue, E, posBits, minFreq, repeatRate, counts.p, flags.p, st);
-	c->sampleRate = sampleRateInit;
-	st->sample_rate = sampleRateInit;
-	st->build_seconds = clock.stop();
-	c->timer.collect();
+	binHistogram(c, B.get(), histOut);
+	B->seconds = clock.stop();
+	c->indexBuild = B;
 }
 
-void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st)
+void fgIndexBeginMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, u64* histOut)
 {
 	if (window < 1 || window > MAXW) throw FgError{FG_ERR_ARG, "wrong minimizer length"};
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	const u32 n = c->nReads;
-	memset(st, 0, sizeof(*st));
-	c->indexBuilt = false;
-	c->timer.evs.clear();
+	clearIndex(c);
+	c->timer.reset();
+	c->indexBuild.reset();
+	std::shared_ptr<IndexBuild> B(new IndexBuild);
 	BuildClock clock(c);
-	Prim prim{c};
-
+	B->solid = false; B->minCoverage = minCoverage; B->repeatRate = repeatRate;
+	B->posBits = bitsFor((u64)c->maxLen);
 	DevBuf<unsigned long long> scal;
 	scal.alloc(4);
 	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
-	DevBuf<uint8_t> flags;
-	flags.alloc(c->totalKmers);
+	B->flags.alloc(c->totalKmers);
 	{
 		DevBuf<u64> hashes;
 		hashes.alloc(window == 1 ? 1 : c->totalKmers);
@@ -768,26 +974,48 @@ void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeat
 		{
 			ScopedK t(c->timer, "k_minimizers");
 			hipLaunchKernelGGL(k_minimizers, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							   window, hashes.p, flags.p, scal.p + 2);
+							   window, hashes.p, B->flags.p, scal.p + 2);
 		}
 		HIP_CHECK(hipStreamSynchronize(s));
 	}
-	const u64 E = fetch(c, scal.p + 2);
-	DevBuf<u64> ecanon, evalue;
-	ecanon.alloc(E); evalue.alloc(E);
-	const int posBits = bitsFor((u64)c->maxLen);
-	if (n && E)
-	{
-		ScopedK t(c->timer, "k_emit");
-		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, flags.p,
-						   posBits, ecanon.p, evalue.p, scal.p + 3);
-	}
-	finishIndex(c, prim, ecanon, evalue, E, posBits, minCoverage, repeatRate, nullptr, flags.p, st);
-	// vertex_index.cpp:480-482: _sampleRate = (float)totalLen / totalEntries
-	size_t totalLen = c->totalBases, totalEntries = c->nEntries;
-	float minimizerRate = (float)totalLen / totalEntries;
-	c->sampleRate = minimizerRate;
-	st->sample_rate = minimizerRate;
-	st->build_seconds = clock.stop();
+	binHistogram(c, B.get(), histOut);
+	B->seconds = clock.stop();
+	c->indexBuild = B;
+}
+
+void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, fg_index_stats* st)
+{
+	fgIndexBeginSolid(c, minFreq, selectRate, tandemFreq, repeatRate, sampleRateInit, nullptr);
+	fgIndexBuildRange(c, 0, FG_INDEX_BINS, nullptr);
+	fgIndexFinish(c, nullptr, st);
+}
+
+void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, fg_index_stats* st)
+{
+	fgIndexBeginMinimizers(c, minCoverage, window, repeatRate, nullptr);
+	fgIndexBuildRange(c, 0, FG_INDEX_BINS, nullptr);
+	fgIndexFinish(c, nullptr, st);
+}
+
+// An index given as CSR arrays (host or device memory): what a rank assembles from the all-gathered pieces
+// of a sharded build, or a saved index.  keys ascending, key_off[nKeys + 1], entries (record << 32 | pos)
+// ascending per key, as fg_export_index writes them.
+void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64 nEnt, const u64* entries, u64 nRep,
+				   const u64* repKeys, float sampleRate, int onDevice)
+{
+	hipStream_t s = c->stream;
+	clearIndex(c);
+	c->timer.reset();
+	c->indexBuild.reset();
+	const hipMemcpyKind kind = onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+	c->dKeys.alloc(nKeys); c->dKeyOff.alloc(nKeys + 1); c->dEntries.alloc(nEnt); c->dRepKeys.alloc(nRep);
+	if (nKeys) HIP_CHECK(hipMemcpyAsync(c->dKeys.p, keys, nKeys * 8, kind, s));
+	HIP_CHECK(hipMemcpyAsync(c->dKeyOff.p, keyOff, (nKeys + 1) * 8, kind, s));
+	if (nEnt) HIP_CHECK(hipMemcpyAsync(c->dEntries.p, entries, nEnt * 8, kind, s));
+	if (nRep) HIP_CHECK(hipMemcpyAsync(c->dRepKeys.p, repKeys, nRep * 8, kind, s));
+	c->nKeys = nKeys; c->nEntries = nEnt; c->nRep = nRep;
+	c->sampleRate = sampleRate;
+	fgIndexLookupStructures(c, nullptr);
 	c->timer.collect();
 }

@@ -36,7 +36,8 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
 
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
                "fg_container_info", "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
-               "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
+               "fg_index_begin_solid", "fg_index_begin_minimizers", "fg_index_build_range", "fg_index_finish",
+               "fg_import_index", "fg_index_device_arrays", "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
                "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances"]
 
 
@@ -106,6 +107,13 @@ def load_library():
                                            C.c_float, C.POINTER(IndexStats)]
         L.fg_build_index_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                                 C.POINTER(IndexStats)]
+        L.fg_index_begin_solid.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        L.fg_index_begin_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+        L.fg_index_build_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.fg_index_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(IndexStats)]
+        L.fg_import_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.c_void_p, C.c_float, C.c_int]
+        L.fg_index_device_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.fg_clear_index.argtypes = [C.c_void_p]
         L.fg_export_index.argtypes = [C.c_void_p] + [C.c_void_p] * 7
         L.fg_overlaps.argtypes = [C.c_void_p, C.POINTER(DetectorParams), C.c_void_p, C.c_uint32,
@@ -329,6 +337,61 @@ class VertexIndex:
         return self.buildIndexUnevenCoverage(2, cfg["meta_read_top_kmer_rate"],
                                              int(cfg["meta_read_filter_kmer_freq"]),
                                              cfg["repeat_kmer_rate"])
+
+    # ---- the build in steps (sharded over GPUs: flye_amd/dist.py) -------------------------------------
+    INDEX_BINS = 4096
+
+    def begin(self, cfg: dict) -> np.ndarray:
+        """Selection step of the build main_assemble.cpp:195-223 selects; returns the number of accepted
+        k-mer positions per key bin."""
+        hist = np.zeros(self.INDEX_BINS, np.uint64)
+        L, h = self.ctx.L, self.ctx.h
+        if cfg["use_minimizers"]:
+            self.ctx._check(L.fg_index_begin_minimizers(h, 1, int(cfg["minimizer_window"]), cfg["repeat_kmer_rate"],
+                                                        hist.ctypes.data))
+        else:
+            self.countKmers()
+            self.ctx._check(L.fg_index_begin_solid(h, 2, cfg["meta_read_top_kmer_rate"],
+                                                   int(cfg["meta_read_filter_kmer_freq"]), cfg["repeat_kmer_rate"],
+                                                   self._sample_rate_init, hist.ctypes.data))
+        return hist
+
+    def build_range(self, bin_lo: int, bin_hi: int) -> np.ndarray:
+        sums = np.zeros(2, np.uint64)
+        self.ctx._check(self.ctx.L.fg_index_build_range(self.ctx.h, int(bin_lo), int(bin_hi), sums.ctypes.data))
+        return sums
+
+    def finish(self, total_sums=None):
+        st = IndexStats()
+        ts = None if total_sums is None else np.ascontiguousarray(total_sums, np.uint64)
+        self.ctx._check(self.ctx.L.fg_index_finish(self.ctx.h, None if ts is None else ts.ctypes.data, C.byref(st)))
+        self.stats = st.as_dict()
+        return self.stats
+
+    def import_index(self, ex: "IndexExport", sample_rate: float, on_device=False, ptrs=None):
+        """fg_import_index from host arrays (``ex``) or device pointers (``ptrs`` = keys, key_off, entries,
+        repetitive as integers, with the counts in ``ex`` = (n_keys, n_entries, n_rep))."""
+        L, h = self.ctx.L, self.ctx.h
+        if on_device:
+            nk, ne, nr = ex
+            self.ctx._check(L.fg_import_index(h, nk, ptrs[0], ptrs[1], ne, ptrs[2], nr, ptrs[3], float(sample_rate), 1))
+        else:
+            k = np.ascontiguousarray(ex.keys, np.uint64)
+            o = np.ascontiguousarray(ex.key_off, np.uint64)
+            e = np.ascontiguousarray(ex.entries, np.uint64)
+            r = np.ascontiguousarray(ex.repetitive, np.uint64)
+            self.ctx._check(L.fg_import_index(h, len(k), k.ctypes.data, o.ctypes.data, len(e), e.ctypes.data, len(r),
+                                              r.ctypes.data, float(sample_rate), 0))
+            nk, ne, nr = len(k), len(e), len(r)
+        self.stats = dict(self.stats or {}, selected_kmers=nk, index_entries=ne, repetitive_kmers=nr,
+                          sample_rate=float(np.float32(sample_rate)))
+
+    def device_arrays(self):
+        """(n_keys, n_entries, n_rep), (keys, key_off, entries, repetitive) device pointers of the built index."""
+        n = [C.c_uint64() for _ in range(3)]
+        p = [C.c_void_p() for _ in range(4)]
+        self.ctx._check(self.ctx.L.fg_index_device_arrays(self.ctx.h, *[C.byref(x) for x in n], *[C.byref(x) for x in p]))
+        return tuple(x.value for x in n), tuple(x.value or 0 for x in p)
 
     def clear(self):
         self.ctx._check(self.ctx.L.fg_clear_index(self.ctx.h))

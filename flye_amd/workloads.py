@@ -28,6 +28,18 @@ def dmel_ont30(seed=3, scale=1.0):
     return rs.filter_min_len(min_ovlp), min_ovlp, "raw"
 
 
+def synth10g_ont(seed=11, scale=1.0):
+    """configs[3]: "Synthetic 10 Gb ONT-error-profile reads": 334 Mb genome, 30x ONT-raw model
+    (10 % error, log-normal lengths), ~15 % repeats -- 10 Gbp of reads at scale 1."""
+    glen = int(334_000_000 * scale)
+    rs = synth.simulate(seed=seed, genome_len=glen, coverage=30, kind="ont_raw",
+                        n_repeat_families=max(1, int(500 * scale)), repeat_len=(500, 10000),
+                        repeat_copies=(10, 40), repeat_div_permille=30,
+                        n_homopolymers=int(40000 * scale), n_tandems=int(40000 * scale))
+    min_ovlp = config.min_overlap_from_reads(rs.length, "raw")
+    return rs.filter_min_len(min_ovlp), min_ovlp, "raw"
+
+
 def hifi30(seed=5, genome_len=4_640_000):
     """HiFi-parameter workload (asm_hifi.cfg) on an E. coli sized genome."""
     scale = genome_len / 4_640_000

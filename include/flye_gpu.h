@@ -109,6 +109,38 @@ int fg_build_index_solid(fg_ctx* ctx, int32_t min_freq, float select_rate,
 int fg_build_index_minimizers(fg_ctx* ctx, int32_t min_coverage, int32_t window,
                               float repeat_rate, struct fg_index_stats* out);
 
+/* The same builds in steps, for sharding over GPUs and for bounded memory:
+ *   begin        the k-mer selection over ALL reads of the container (it needs every read: exact counts,
+ *                per-read frequency thresholds / minimizers); hist[FG_INDEX_BINS] receives the number of
+ *                accepted k-mer positions per key bin (bin = canonical k-mer >> max(0, 2k - 12));
+ *   build_range  sorts and run-length encodes the keys of bins [bin_lo, bin_hi) -- each rank its own
+ *                range; sums[2] = this context's running share of filterFrequentKmers' two integer sums
+ *                (vertex_index.cpp:175-184), to be added up over the ranks;
+ *   finish       total_sums (NULL = this context's own) fix the repetitive frequency; the context then
+ *                holds a usable index over the ranges it built (fg_export_index / fg_index_device_arrays
+ *                give the pieces; the all-gathered concatenation goes into fg_import_index).
+ * fg_build_index_solid / _minimizers = begin + build_range(0, FG_INDEX_BINS) + finish(NULL). */
+#define FG_INDEX_BINS 4096
+int fg_index_begin_solid(fg_ctx* ctx, int32_t min_freq, float select_rate, int32_t tandem_freq,
+                         float repeat_rate, float sample_rate_init, uint64_t* hist);
+int fg_index_begin_minimizers(fg_ctx* ctx, int32_t min_coverage, int32_t window, float repeat_rate,
+                              uint64_t* hist);
+int fg_index_build_range(fg_ctx* ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t* sums);
+int fg_index_finish(fg_ctx* ctx, const uint64_t* total_sums, struct fg_index_stats* out);
+
+/* An index given as CSR arrays in the layout fg_export_index writes (keys ascending, key_off[n_keys + 1],
+ * entries ascending per key), in host memory or -- on_device != 0 -- in this context's device memory
+ * (e.g. torch tensors filled by an RCCL all-gather).  sample_rate = VertexIndex::getSampleRate(). */
+int fg_import_index(fg_ctx* ctx, uint64_t n_keys, const uint64_t* keys, const uint64_t* key_off,
+                    uint64_t n_entries, const uint64_t* entries, uint64_t n_repetitive,
+                    const uint64_t* repetitive_keys, float sample_rate, int on_device);
+
+/* Device pointers of the built index (valid until the next build / import / clear), for collectives
+ * that run on device memory. */
+int fg_index_device_arrays(fg_ctx* ctx, uint64_t* n_keys, uint64_t* n_entries, uint64_t* n_repetitive,
+                           const uint64_t** keys, const uint64_t** key_off, const uint64_t** entries,
+                           const uint64_t** repetitive_keys);
+
 /* VertexIndex::clear() (vertex_index.cpp:486-496) */
 int fg_clear_index(fg_ctx* ctx);
 

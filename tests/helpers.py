@@ -140,3 +140,41 @@ def pairs_readset(pairs):
     for a, b in pairs:
         seqs += [a, b]
     return synth.ReadSet.from_arrays(seqs)
+
+
+# ---- sampled oracle parity at sizes where the oracle cannot hold (or build) the whole index ---------------
+def canonical_kmers(rs, r, k):
+    """Canonical k-mers (Kmer repr, kmer.h:32-52) of every forward position of read r, incl. the one the
+    reference's iteration drops (a superset is harmless here)."""
+    L = int(rs.length[r])
+    w = rs.words[int(rs.word_off[r]):int(rs.word_off[r + 1])]
+    sh = np.arange(32, dtype=np.uint64) * np.uint64(2)
+    b = ((w[:, None] >> sh[None, :]) & np.uint64(3)).reshape(-1)[:L].astype(np.uint64)
+    n = L - k + 1
+    if n <= 0:
+        return np.empty(0, np.uint64)
+    fw = np.zeros(n, np.uint64)
+    rv = np.zeros(n, np.uint64)
+    for t in range(k):
+        fw = (fw << np.uint64(2)) | b[t:t + n]
+        rv = rv | ((np.uint64(3) - b[t:t + n]) << np.uint64(2 * t))
+    return np.minimum(fw, rv)
+
+
+def sub_index(ex, rs, reads, k):
+    """The part of an exported index the given query reads can touch: getSeqOverlaps looks up the k-mers
+    of the query only (overlap.cpp:176-196), so the oracle gives the same records on this sub-index as on
+    the whole one -- at a size it can import in seconds."""
+    from oracle import oracle as O
+    km = np.unique(np.concatenate([canonical_kmers(rs, int(r), k) for r in reads]))
+    idx = np.searchsorted(ex.keys, km)
+    ok = idx < len(ex.keys)
+    ok[ok] &= ex.keys[idx[ok]] == km[ok]
+    sel = idx[ok]
+    off = ex.key_off.astype(np.int64)
+    cnt = off[sel + 1] - off[sel]
+    new_off = np.zeros(len(sel) + 1, np.int64)
+    new_off[1:] = np.cumsum(cnt)
+    pos = np.repeat(off[sel] - new_off[:-1], cnt) + np.arange(int(new_off[-1]), dtype=np.int64)
+    return O.IndexExport(np.ascontiguousarray(ex.keys[sel]), new_off.astype(np.uint64),
+                         np.ascontiguousarray(ex.entries[pos]), ex.repetitive)

@@ -63,3 +63,140 @@ def test_two_rank_sharding_gloo(built, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert int(open(tmp_path / "ok").read()) > 100
+
+
+# ---- sharded index build: the exchange on CPU tensors ----------------------------------------------------
+def _piece_worker(rank, world, port, out_dir):
+    """Each rank holds the piece of the oracle's index that a key-range-sharded build would leave it with
+    (bins cut by dist.balanced_bin_ranges); sums all-reduce + all-gather of the pieces over gloo must give
+    every rank the oracle's whole index."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as td
+    from flye_amd import config, dist, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    rs = synth.simulate(seed=77, genome_len=50_000, coverage=20, kind="pb_raw", n_tandems=20).filter_min_len(1000)
+    cfg = config.preset("raw")
+    k = 17
+    o = O.Oracle(k, threads=2)
+    o.set_reads(rs)
+    o.build_index(cfg)
+    full = o.export_index()
+    # entries per key bin stand in for the device's histogram of accepted positions
+    shift = max(0, 2 * k - 12)
+    cnt = np.diff(full.key_off.astype(np.int64))
+    hist = np.bincount((full.keys >> np.uint64(shift)).astype(np.int64), weights=cnt, minlength=4096)
+    ranges = dist.balanced_bin_ranges(hist, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 4096 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    lo, hi = ranges[rank]
+    sel = ((full.keys >> np.uint64(shift)) >= lo) & ((full.keys >> np.uint64(shift)) < hi)
+    idx = np.nonzero(sel)[0]
+    rsel = ((full.repetitive >> np.uint64(shift)) >= lo) & ((full.repetitive >> np.uint64(shift)) < hi)
+    if len(idx):
+        a, b = int(full.key_off[idx[0]]), int(full.key_off[idx[-1] + 1])
+        pk, po, pe = full.keys[idx], full.key_off[idx[0]:idx[-1] + 2] - np.uint64(a), full.entries[a:b]
+    else:
+        pk, po, pe = full.keys[:0], np.zeros(1, np.uint64), full.entries[:0]
+    piece = tuple(torch.from_numpy(np.ascontiguousarray(x).view(np.int64)) for x in (pk, po, pe, full.repetitive[rsel]))
+    # the two sums of filterFrequentKmers, piecewise, then over all ranks
+    part = torch.tensor([int(len(pe)), int(len(pk))], dtype=torch.int64)
+    td.all_reduce(part)
+    assert part.tolist() == [len(full.entries), len(full.keys)]
+    keys, off, ent, rep, (K, E, R), moved = dist.allgather_pieces(piece, rank, world, torch.device("cpu"))
+    assert (K, E, R) == (len(full.keys), len(full.entries), len(full.repetitive))
+    assert np.array_equal(keys[:K].numpy().view(np.uint64), full.keys)
+    assert np.array_equal(off.numpy().view(np.uint64), full.key_off)
+    assert np.array_equal(ent[:E].numpy().view(np.uint64), full.entries)
+    assert np.array_equal(rep[:R].numpy().view(np.uint64), full.repetitive)
+    assert moved >= 8 * (2 * K + E + R)
+    # the host form of the same assembly
+    pieces = [None] * world
+    td.all_gather_object(pieces, (pk, po, pe, full.repetitive[rsel]))
+    from flye_amd.gpu import IndexExport
+    cat = dist.concat_pieces([IndexExport(*p) for p in pieces])
+    assert np.array_equal(cat.keys, full.keys) and np.array_equal(cat.key_off, full.key_off)
+    assert np.array_equal(cat.entries, full.entries) and np.array_equal(cat.repetitive, full.repetitive)
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(K))
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_index_pieces_allgather_gloo(built, tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_piece_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(int(open(tmp_path / f"ok{r}").read()) > 1000 for r in range(world))
+
+
+def test_balanced_bin_ranges():
+    from flye_amd import dist
+    rng = np.random.default_rng(0)
+    hist = rng.integers(0, 1000, size=4096)
+    hist[:100] *= 50                                    # canonical k-mers crowd the low bins
+    for world in (1, 2, 3, 8):
+        r = dist.balanced_bin_ranges(hist, world)
+        assert r[0][0] == 0 and r[-1][1] == 4096 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        share = np.array([hist[a:b].sum() for a, b in r]) / hist.sum()
+        assert share.max() < 1.0 / world + 0.05
+    assert dist.balanced_bin_ranges(np.zeros(4096), 4)[-1][1] == 4096
+
+
+# ---- the device path on two ranks (one GPU box: both ranks on device 0, collectives through gloo) ---------
+def _gpu_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
+    import torch.distributed as td
+    from flye_amd import config, dist, gpu, synth
+    from helpers import index_digest
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for preset, kind in (("raw", "pb_raw"), ("hifi", "hifi")):
+        rs = synth.simulate(seed=91, genome_len=60_000, coverage=25, kind=kind, n_tandems=30).filter_min_len(1000)
+        cfg = config.preset(preset)
+        ctx = gpu.Context(17, 0)
+        ctx.set_reads(rs)
+        vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+        st = dist.build_index_sharded(vi, cfg, rank, world, on_device=False)
+        det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
+        det.p.max_divergence = 0.3
+        mine = dist.shard_queries(rs.n, rank, world)
+        res = det.getSeqOverlapsBatch(mine)
+        digest = index_digest(vi.export())
+        # single-process reference on the same GPU: ordinary build, all queries
+        ctx1 = gpu.Context(17, 0)
+        ctx1.set_reads(rs)
+        vi1 = gpu.VertexIndex(ctx1, float(int(cfg["assemble_kmer_sample"])))
+        st1 = vi1.build(cfg)
+        det1 = gpu.OverlapDetector.for_assemble(ctx1, vi1, cfg)
+        det1.p.max_divergence = 0.3
+        one = det1.getSeqOverlapsBatch(np.arange(0, 2 * rs.n, 2, dtype=np.uint32))
+        assert digest == index_digest(vi1.export()), preset
+        for f in ("selected_kmers", "index_entries", "repetitive_kmers", "repetitive_frequency"):
+            assert st[f] == st1[f], (preset, f)
+        assert np.float32(st["sample_rate"]).tobytes() == np.float32(st1["sample_rate"]).tobytes()
+        lines1 = one.lines()
+        want = [l for i in range(rank, rs.n, world) for l in lines1[int(one.query_off[i]):int(one.query_off[i + 1])]]
+        assert res.lines() == want and len(want) > 0, preset
+        out[preset] = (st["piece"], st["collective_bytes"], len(want))
+        ctx.close(); ctx1.close()
+    open(os.path.join(out_dir, f"gpu_ok{rank}"), "w").write(repr(out))
+    td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_build_and_overlaps_on_device(built, tmp_path):
+    """Two processes, each with its own context on the GPU: key-range-sharded index build (begin / build_range
+    / sums all-reduce / finish / pieces all-gather / import) and read-sharded overlap stage; index and
+    overlaps must equal the single-process ones."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [eval(open(tmp_path / f"gpu_ok{k}").read()) for k in range(2)]
+    for preset in ("raw", "hifi"):
+        assert r[0][preset][0] != r[1][preset][0] and min(r[0][preset][0][1], r[1][preset][0][1]) > 0   # both built a real piece
