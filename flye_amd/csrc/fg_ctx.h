@@ -12,6 +12,10 @@
 #include <vector>
 #include <map>
 #include <memory>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "../../include/flye_gpu.h"
 
@@ -140,6 +144,59 @@ struct ScopedK {
 	~ScopedK() { try { t.end(id); } catch (...) {} }
 };
 
+// Worker threads of the host shim, kept between calls: spawning 2 x 16 std::threads per fg_overlaps call and
+// faulting in fresh result-sized vectors cost more than the shim's own arithmetic.
+struct ShimPool {
+	std::vector<std::thread> threads;
+	std::mutex mu;
+	std::condition_variable cvGo, cvDone;
+	const std::function<void(unsigned)>* job = nullptr;
+	unsigned long long epoch = 0;
+	unsigned pending = 0, nActive = 0;
+	bool stop = false;
+
+	void ensure(unsigned n)
+	{
+		while (threads.size() < n)
+		{
+			const unsigned id = (unsigned)threads.size();
+			threads.emplace_back([this, id]
+			{
+				unsigned long long seen = 0;
+				std::unique_lock<std::mutex> lk(mu);
+				while (true)
+				{
+					cvGo.wait(lk, [&] { return stop || (epoch != seen && id < nActive); });
+					if (stop) return;
+					seen = epoch;
+					const std::function<void(unsigned)>* f = job;
+					lk.unlock();
+					(*f)(id);
+					lk.lock();
+					if (--pending == 0) cvDone.notify_all();
+				}
+			});
+		}
+	}
+	// fn(0 .. n-1), one call per thread; returns when all are done.  n == 1 runs inline.
+	void run(unsigned n, const std::function<void(unsigned)>& fn)
+	{
+		if (n <= 1) { fn(0); return; }
+		ensure(n);
+		std::unique_lock<std::mutex> lk(mu);
+		job = &fn; nActive = n; pending = n; ++epoch;
+		cvGo.notify_all();
+		cvDone.wait(lk, [&] { return pending == 0; });
+		// threads beyond n that woke up went back to sleep (id >= nActive); the epoch they skipped is harmless
+	}
+	~ShimPool()
+	{
+		{ std::lock_guard<std::mutex> g(mu); stop = true; }
+		cvGo.notify_all();
+		for (auto& t : threads) if (t.joinable()) t.join();
+	}
+};
+
 struct fg_ctx {
 	int device = 0;
 	int k = 17;
@@ -218,6 +275,12 @@ struct fg_ctx {
 	DevBuf<u64> dEditSlab;		// per-block string planes + delta planes of the bit-vector kernel
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;
+	// host shim: worker threads and result-sized scratch kept between calls
+	ShimPool shimPool;
+	std::vector<float> shimDiv;
+	std::vector<uint8_t> shimKeep;
+	std::vector<u32> shimNStat;
+	std::vector<u64> shimNMatch;
 
 	~fg_ctx() { if (stream) (void)hipStreamDestroy(stream); }
 };

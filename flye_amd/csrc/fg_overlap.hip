@@ -1056,10 +1056,13 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	const bool nucl = p->nucl_alignment;
 	const bool partition = p->partition_bad_mappings;	// only with maxOverlaps == 0 (fg_api.hip)
 	const int STAT_WND = 10000;
-	std::vector<float> div(nPrim);
-	std::vector<uint8_t> keep(nPrim, 0);
-	std::vector<u32> nStat(nq, 0);
-	std::vector<u64> nMatch(keepAln ? nq : 0, 0);
+	// result-sized scratch lives in the context (grow-only, never zero-filled: pass 1 writes every element)
+	if (c->shimDiv.size() < nPrim) { c->shimDiv.resize(nPrim + nPrim / 8); c->shimKeep.resize(c->shimDiv.size()); }
+	if (c->shimNStat.size() < nq) { c->shimNStat.resize(nq + nq / 8); c->shimNMatch.resize(c->shimNStat.size()); }
+	float* div = c->shimDiv.data();
+	uint8_t* keep = c->shimKeep.data();
+	u32* nStat = c->shimNStat.data();
+	u64* nMatch = c->shimNMatch.data();
 	std::vector<std::vector<float>> statVals;
 	// host threads of the shim: the hardware threads, capped by the cgroup CPU quota (a container that
 	// shows 256 threads but is granted 16 CPUs of time runs the shim slower on 32 threads than on 16)
@@ -1091,6 +1094,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			wnd.assign(curLen / STAT_WND + 1, Wnd{0, 0.0f});
 			size_t detected = 0;
 			u32 prevExt = 0xFFFFFFFFu;
+			if (keepAln) nMatch[qi] = 0;
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
 				const PrimRec& r = hPrim[j];
@@ -1099,7 +1103,11 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				// with several primaries (onlyMaxExt = false) is never cut in the middle
 				if (r.extId != prevExt)
 				{
-					if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps) break;
+					if (maxOverlaps != 0 && detected >= (size_t)maxOverlaps)
+					{
+						for (u64 jj = j; jj < hPrimOff[qi + 1]; ++jj) keep[jj] = 0;	// the scratch is not zero-filled
+						break;
+					}
 					prevExt = r.extId;
 				}
 				// overlap.cpp:414-423
@@ -1112,6 +1120,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				div[j] = d;
 				if (d < maxDiv) { keep[j] = 1; ++detected; }
 				else if (partition) { keep[j] = 2; ++detected; }	// handed back for the caller's checkIdyAndTrim
+				else keep[j] = 0;
 				if (keep[j] && keepAln) nMatch[qi] += mOff[j + 1] - mOff[j];
 				const size_t w = r.curBegin / STAT_WND;
 				if (r.curEnd - r.curBegin > wnd[w].range) { wnd[w].range = r.curEnd - r.curBegin; wnd[w].div = d; }
@@ -1122,13 +1131,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			nStat[qi] = ns;
 		}
 	};
-	auto runThreads = [&](const std::function<void(unsigned)>& fn)
-	{
-		if (nThreads == 1) { fn(0); return; }
-		std::vector<std::thread> pool;
-		for (unsigned t = 0; t < nThreads; ++t) pool.emplace_back(fn, t);
-		for (auto& th : pool) th.join();
-	};
+	auto runThreads = [&](const std::function<void(unsigned)>& fn) { c->shimPool.run(nThreads, fn); };
 	runThreads(pass1);
 	own->queryOff[0] = 0;
 	for (u32 qi = 0; qi < nq; ++qi)
