@@ -26,7 +26,25 @@ typedef int32_t i32;
 #define FG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
 #define FG_CNT_BITS 24
 #define FG_CNT_MASK 0xFFFFFFu
-#define FG_CNT_REPETITIVE 0xFFFFFFu	// slot marks a k-mer of _repetitiveKmers
+#define FG_CNT_REPETITIVE 0xFFFFFFu	// probe result for a k-mer of _repetitiveKmers
+#define FG_IDX_BITS 30				// narrow slot: key << 30 | key index inside its part (all ones = repetitive)
+#define FG_IDX_MASK 0x3FFFFFFFULL
+#define FG_TABLE_MAX_PARTS 16
+
+// The lookup table as the kernels see it (passed by value).  Narrow form (2k <= 34 bits, i.e. k <= 17): one
+// u64 per slot; keys are split into parts by key RANGE so that an index inside a part fits 30 bits
+// (one part up to 2^30 - 2 keys; the split follows the sorted key array, equal key counts per part).
+// Wide form (k > 17): {key, key index} pairs, one part.  Linear probing inside a part, load <= 0.5.
+struct FgTable {
+	const unsigned long long* slots;
+	const ulonglong2* wide;
+	const unsigned long long* keyOff;
+	unsigned nParts;
+	unsigned long long bound[FG_TABLE_MAX_PARTS + 1];	// part p: keys in [bound[p], bound[p + 1])
+	unsigned long long slotBase[FG_TABLE_MAX_PARTS];
+	unsigned long long keyBase[FG_TABLE_MAX_PARTS];
+	unsigned groups[FG_TABLE_MAX_PARTS];				// 8-slot groups of part p
+};
 
 struct FgError { int code; std::string msg; };
 
@@ -234,7 +252,9 @@ struct fg_ctx {
 	DevBuf<u64> dKeyOff;	// nKeys+1
 	DevBuf<u64> dEntries;	// (record<<32 | pos), ascending per key
 	DevBuf<u64> dRepKeys;	// ascending
-	DevBuf<ulonglong2> dTable;	// {key, off<<24 | cnt}
+	DevBuf<u64> dTable;			// narrow slots, or ulonglong2 {key, index} pairs when tableWide
+	bool tableWide = false;
+	FgTable table{};
 	DevBuf<u32> dIndexedBits;	// one bit per forward k-mer position: contributes an entry
 
 	std::shared_ptr<void> indexBuild;	// state between the steps of an index build (fg_index.hip)
@@ -396,16 +416,58 @@ __device__ __forceinline__ void fg_kmer_pair(const u64* __restrict__ w, i32 q, i
 	rv = ~x & mask;
 }
 
-// probe: returns the slot value (off<<24|cnt) or 0 when absent
-__device__ __forceinline__ u64 fg_probe(const ulonglong2* __restrict__ table, u64 mask, u64 key)
+// probe: returns off << 24 | cnt of the k-mer's list, FG_CNT_REPETITIVE in the low bits for a k-mer of
+// _repetitiveKmers, or 0 when absent.  One 8-byte slot read decides a miss (4 in 5 query k-mers: the
+// table is half the size of a 16-byte layout -- E. coli 50x: 134 MB, inside the 256 MiB Infinity Cache);
+// a hit reads the list bounds from the key-ordered offsets.
+template <bool WIDE>
+__device__ __forceinline__ u64 fg_probe(const FgTable& T, u64 key)
 {
-	u64 h = fg_mix(key) & mask;
+	u32 p = 0;
+	if (T.nParts > 1)
+		while (p + 1 < T.nParts && key >= T.bound[p + 1]) ++p;
+	const u64 mix = fg_mix(key);
+	const u32 nGroups = T.groups[p];
+	u32 g = __umulhi((u32)(mix >> 32), nGroups);
+	if (WIDE)
+	{
+		// {key, index} pairs, linear probing over the part's slots
+		const u32 slotsInPart = nGroups * 8u;
+		u32 h = g * 8u + ((u32)mix & 7u);
+		while (true)
+		{
+			const ulonglong2 s = T.wide[T.slotBase[p] + h];
+			if (s.x == FG_EMPTY_KEY) return 0;
+			if (s.x != key) { h = h + 1 == slotsInPart ? 0 : h + 1; continue; }
+			if (s.y == FG_EMPTY_KEY) return FG_CNT_REPETITIVE;
+			const u64 o = T.keyOff[s.y];
+			return (o << FG_CNT_BITS) | (T.keyOff[s.y + 1] - o);
+		}
+	}
+	// narrow: the key's 8-slot group is one 64-byte line, fetched whole; insertion fills a group before it
+	// spills into the next, so an empty slot anywhere in the group settles a miss without a second access
 	while (true)
 	{
-		ulonglong2 s = table[h];
-		if (s.x == key) return s.y;
-		if (s.x == FG_EMPTY_KEY) return 0;
-		h = (h + 1) & mask;
+		const ulonglong2* grp = (const ulonglong2*)(T.slots + T.slotBase[p] + (u64)g * 8u);
+		const ulonglong2 a = grp[0], b = grp[1], c = grp[2], d = grp[3];
+		const u64 sl[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+		u64 hit = FG_EMPTY_KEY;
+		bool empty = false;
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+		{
+			if ((sl[i] >> FG_IDX_BITS) == key) hit = sl[i];
+			empty |= sl[i] == FG_EMPTY_KEY;
+		}
+		if (hit != FG_EMPTY_KEY)
+		{
+			if ((hit & FG_IDX_MASK) == FG_IDX_MASK) return FG_CNT_REPETITIVE;
+			const u64 idx = T.keyBase[p] + (hit & FG_IDX_MASK);
+			const u64 o = T.keyOff[idx];
+			return (o << FG_CNT_BITS) | (T.keyOff[idx + 1] - o);
+		}
+		if (empty) return 0;
+		g = g + 1 == nGroups ? 0 : g + 1;
 	}
 }
 

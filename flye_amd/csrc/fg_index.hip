@@ -488,27 +488,49 @@ __global__ void k_entries(const u64* __restrict__ evalue, u64 n, const u32* __re
 	entries[entBase + off[j] + (i - kstart[j])] = ((v >> posBits) << 32) | (v & ((1ULL << posBits) - 1));
 }
 
+// keys with a non-empty list (by their index in the sorted key array) and the repetitive keys -> slots
+template <bool WIDE>
 __global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restrict__ keyOff, u64 nKeys,
-							   const u64* __restrict__ repKeys, u64 nRep, ulonglong2* __restrict__ table,
-							   u64 mask)
+							   const u64* __restrict__ repKeys, u64 nRep, FgTable T, u64* __restrict__ slots,
+							   ulonglong2* __restrict__ wide)
 {
 	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
-	u64 key, val;
+	u64 key, idx;
 	if (j < nKeys)
 	{
-		const u64 cnt = keyOff[j + 1] - keyOff[j];
-		if (cnt == 0) return;	// an empty list behaves like an absent key (overlap.cpp:183)
-		key = keys[j]; val = (keyOff[j] << FG_CNT_BITS) | cnt;
+		if (keyOff[j + 1] == keyOff[j]) return;	// an empty list behaves like an absent key (overlap.cpp:183)
+		key = keys[j]; idx = j;
 	}
-	else if (j < nKeys + nRep) { key = repKeys[j - nKeys]; val = FG_CNT_REPETITIVE; }
+	else if (j < nKeys + nRep) { key = repKeys[j - nKeys]; idx = FG_EMPTY_KEY; }
 	else return;
-	u64 h = fg_mix(key) & mask;
-	while (true)
+	u32 p = 0;
+	while (p + 1 < T.nParts && key >= T.bound[p + 1]) ++p;
+	const u64 mix = fg_mix(key);
+	const u32 slotsInPart = T.groups[p] * 8u;
+	u32 h = __umulhi((u32)(mix >> 32), T.groups[p]) * 8u + ((u32)mix & 7u);
+	if (WIDE)
 	{
-		u64 old = atomicCAS((unsigned long long*)&table[h].x, (unsigned long long)FG_EMPTY_KEY,
-							(unsigned long long)key);
-		if (old == FG_EMPTY_KEY) { table[h].y = val; break; }
-		h = (h + 1) & mask;
+		while (true)
+		{
+			const u64 old = atomicCAS((unsigned long long*)&wide[T.slotBase[p] + h].x, (unsigned long long)FG_EMPTY_KEY,
+									  (unsigned long long)key);
+			if (old == FG_EMPTY_KEY) { wide[T.slotBase[p] + h].y = idx; break; }
+			h = h + 1 == slotsInPart ? 0 : h + 1;
+		}
+	}
+	else
+	{
+		// group by group from the key's own: the first empty slot in group order takes it (a group is full
+		// before anything spills into the next one -- what lets a probe stop at a group with an empty slot)
+		const u64 v = (key << FG_IDX_BITS) | (idx == FG_EMPTY_KEY ? FG_IDX_MASK : (idx - T.keyBase[p]));
+		h &= ~7u;
+		while (true)
+		{
+			const u64 old = atomicCAS((unsigned long long*)&slots[T.slotBase[p] + h], (unsigned long long)FG_EMPTY_KEY,
+									  (unsigned long long)v);
+			if (old == FG_EMPTY_KEY) break;
+			h = h + 1 == slotsInPart ? 0 : h + 1;
+		}
 	}
 }
 
@@ -518,8 +540,7 @@ __global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restri
 __global__ void k_indexed_bits(const u64* __restrict__ words, const u64* __restrict__ wordOff,
 							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 							   const uint8_t* __restrict__ flags /* the build's selection, or null */,
-							   const ulonglong2* __restrict__ table, u64 mask, const u64* __restrict__ entries,
-							   u32* __restrict__ bits)
+							   FgTable T, int wide, const u64* __restrict__ entries, u32* __restrict__ bits)
 {
 	const u32 r = blockIdx.x;
 	const i32 L = len[r];
@@ -533,7 +554,7 @@ __global__ void k_indexed_bits(const u64* __restrict__ words, const u64* __restr
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
 		const bool flip = rv < fw;
-		const u64 v = fg_probe(table, mask, flip ? rv : fw);
+		const u64 v = wide ? fg_probe<true>(T, flip ? rv : fw) : fg_probe<false>(T, flip ? rv : fw);
 		if (v == 0 || (v & FG_CNT_MASK) == FG_CNT_REPETITIVE) continue;
 		if (!fl)
 		{
@@ -862,16 +883,63 @@ void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags)
 {
 	hipStream_t s = c->stream;
 	const u64 nKeep = c->nKeys, nRep = c->nRep;
-	u64 slots = 1024;
-	while (slots < 2 * (nKeep + nRep)) slots <<= 1;
+	const bool wide = 2 * c->k > 64 - FG_IDX_BITS;
+	FgTable T;
+	memset(&T, 0, sizeof(T));
+	T.keyOff = (const unsigned long long*)c->dKeyOff.p;
+	// parts of equal key count along the sorted key array; the repetitive keys fall into the part their value lies in
+	const u64 perPart = wide ? ~0ULL : (getenv("FG_TABLE_PART_KEYS") ? strtoull(getenv("FG_TABLE_PART_KEYS"), nullptr, 10)
+																	 : ((1ULL << FG_IDX_BITS) - 2));
+	const u32 nParts = wide || nKeep == 0 ? 1u : (u32)((nKeep + perPart - 1) / perPart);
+	if (nParts > FG_TABLE_MAX_PARTS) throw FgError{FG_ERR_UNSUPPORTED, "more than 16 * 2^30 distinct k-mers in the index"};
+	T.nParts = nParts;
+	std::vector<u64> partKeys(nParts, 0);
+	for (u32 p = 0; p < nParts; ++p)
+	{
+		T.keyBase[p] = (u64)p * (wide ? 0 : perPart);
+		partKeys[p] = std::min<u64>(nKeep - T.keyBase[p], wide ? nKeep : perPart);
+		T.bound[p] = p == 0 ? 0ULL : fetch(c, c->dKeys.p + T.keyBase[p]);
+	}
+	T.bound[nParts] = ~0ULL;
+	std::vector<u64> hRep(nRep);
+	if (nRep) HIP_CHECK(hipMemcpyAsync(hRep.data(), c->dRepKeys.p, nRep * 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	for (u64 r : hRep)
+	{
+		u32 p = 0;
+		while (p + 1 < nParts && r >= T.bound[p + 1]) ++p;
+		++partKeys[p];
+	}
+	u64 slots = 0;
+	for (u32 p = 0; p < nParts; ++p)
+	{
+		// in 8-slot groups; load 0.25 while that keeps the table small (fewer spilled groups: k_probe 5.3 ms
+		// against 5.8 at load 0.5 on the bench workload), load 0.5 for big indexes (10 Gbp of reads: 1.4 G keys =
+		// 23 GB instead of 46).  FG_TABLE_LOAD_PCT for experiments.
+		const u64 loadPct = getenv("FG_TABLE_LOAD_PCT") ? std::max(5, std::min(90, atoi(getenv("FG_TABLE_LOAD_PCT"))))
+													 : ((nKeep + nRep) * 32 <= (2ULL << 30) ? 25 : 50);
+		const u64 g = std::max<u64>(16, (partKeys[p] * 100 / loadPct + 7) / 8);
+		if (g > 0xFFFFFFFFULL) throw FgError{FG_ERR_UNSUPPORTED, "lookup table part too large"};
+		T.slotBase[p] = slots;
+		T.groups[p] = (u32)g;
+		slots += g * 8;
+	}
 	c->tableSlots = slots;
-	c->dTable.alloc(slots);
-	HIP_CHECK(hipMemsetAsync(c->dTable.p, 0xFF, slots * sizeof(ulonglong2), s));
+	c->tableWide = wide;
+	c->dTable.alloc(slots * (wide ? 2 : 1));
+	HIP_CHECK(hipMemsetAsync(c->dTable.p, 0xFF, slots * (wide ? 16 : 8), s));
+	T.slots = wide ? nullptr : (const unsigned long long*)c->dTable.p;
+	T.wide = wide ? (const ulonglong2*)c->dTable.p : nullptr;
+	c->table = T;
 	if (nKeep + nRep)
 	{
 		ScopedK t(c->timer, "k_table_insert");
-		hipLaunchKernelGGL(k_table_insert, gridFor(nKeep + nRep), WG, 0, s, c->dKeys.p, c->dKeyOff.p, nKeep,
-						   c->dRepKeys.p, nRep, c->dTable.p, slots - 1);
+		if (wide)
+			hipLaunchKernelGGL(k_table_insert<true>, gridFor(nKeep + nRep), WG, 0, s, c->dKeys.p, c->dKeyOff.p, nKeep,
+							   c->dRepKeys.p, nRep, T, (u64*)nullptr, (ulonglong2*)c->dTable.p);
+		else
+			hipLaunchKernelGGL(k_table_insert<false>, gridFor(nKeep + nRep), WG, 0, s, c->dKeys.p, c->dKeyOff.p, nKeep,
+							   c->dRepKeys.p, nRep, T, c->dTable.p, (ulonglong2*)nullptr);
 	}
 	c->dIndexedBits.alloc((c->totalKmers + 31) / 32 + 1);
 	HIP_CHECK(hipMemsetAsync(c->dIndexedBits.p, 0, c->dIndexedBits.bytes(), s));
@@ -879,7 +947,7 @@ void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags)
 	{
 		ScopedK t(c->timer, "k_indexed_bits");
 		hipLaunchKernelGGL(k_indexed_bits, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
-						   flags, c->dTable.p, slots - 1, c->dEntries.p, c->dIndexedBits.p);
+						   flags, c->table, c->tableWide ? 1 : 0, c->dEntries.p, c->dIndexedBits.p);
 	}
 	HIP_CHECK(hipStreamSynchronize(s));
 	c->indexBuilt = true;

@@ -93,10 +93,11 @@ __global__ void k_exscan(const u64* __restrict__ in, u64* __restrict__ out, u32 
 // words/wordOff/len: the QUERY container; kmerOff/indexedBits: the indexed container's k-mer
 // numbering (indexedBits == nullptr when the queries live in their own container: no
 // query can then hit itself)
+template <bool WIDE>
 __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ words,
 						const u64* __restrict__ wordOff, const i32* __restrict__ len,
 						const u64* __restrict__ kmerOff, const u64* __restrict__ qKmerOff, int k,
-						const ulonglong2* __restrict__ table, u64 tmask,
+						FgTable table,
 						const u32* __restrict__ indexedBits, u64* __restrict__ probe,
 						u64* __restrict__ hitCnt, u64* __restrict__ filtCnt)
 {
@@ -123,7 +124,7 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 		// forward position nk (= L-k) is never a forward k-mer position (kmer.h:193-198)
 		const u64 bit = kbase + (u64)qf;
 		const u32 selfWord = (indexedBits && qf < nk) ? indexedBits[bit >> 5] : 0u;
-		u64 v = fg_probe(table, tmask, flip ? rv : fw);
+		u64 v = fg_probe<WIDE>(table, flip ? rv : fw);
 		if (v != 0)
 		{
 			const u32 cnt = (u32)(v & FG_CNT_MASK);
@@ -817,9 +818,14 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64* qWordOff = c->hasQ ? c->dQWordOff.p : c->dWordOff.p;
 	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
 	{ ScopedK t(c->timer, "k_probe");
-	  hipLaunchKernelGGL(k_probe, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,
-						 c->dQKmerOff.p, k, c->dTable.p, c->tableSlots - 1, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p,
-						 c->dProbe.p, c->dCntA.p, c->dCntB.p); }
+	  if (c->tableWide)
+		hipLaunchKernelGGL(k_probe<true>, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,
+						   c->dQKmerOff.p, k, c->table, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p,
+						   c->dProbe.p, c->dCntA.p, c->dCntB.p);
+	  else
+		hipLaunchKernelGGL(k_probe<false>, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,
+						   c->dQKmerOff.p, k, c->table, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p,
+						   c->dProbe.p, c->dCntA.p, c->dCntB.p); }
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }

@@ -580,3 +580,22 @@ def test_repeat_graph_flag_set_within_time_budget(built):
     assert int(gres.recs["edit_distance"].max()) > 512      # beyond ED_EMAX: the bit-vector kernel was needed ...
     assert "k_edit_myers" in kt
     assert dt < 5.0, f"{dt:.2f} s for {len(gres.recs)} records: {kt}"   # ... and the pass stays bounded
+
+
+@pytest.mark.parametrize("name", ["raw_pb", "hifi_rc_max"])
+def test_lookup_table_split_into_parts(built, golden_cases, monkeypatch, name):
+    """The narrow lookup table keeps a 30-bit key index per slot and is split by key range when a part would
+    hold more than 2^30 - 2 keys (D. melanogaster: 565 M keys, one part; 10 Gbp of reads: 1.4 G keys, two).
+    FG_TABLE_PART_KEYS forces the split at golden-case size: results must not change."""
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    from flye_amd import config
+    cfg = config.preset(case["preset"])
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    monkeypatch.setenv("FG_TABLE_PART_KEYS", str(st["selected_kmers"] // 5 + 1))
+    ctx2, vi2, st2, det2 = _gpu_setup(rs, cfg)
+    assert index_digest(vi2.export()) == case["index"]["sha256"]
+    det2.p.max_divergence = bits_to_float(case["max_div_bits"])
+    res = det2.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
+                                   maxOverlaps=case.get("max_overlaps", 0))
+    assert res.lines() == golden_lines(name)
