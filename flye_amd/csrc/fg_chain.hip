@@ -560,7 +560,76 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	i32 ncand = 0;
 	int4 best = make_int4(0, 0, 0, 0);
 	wsort::wave_mem_fence();
-	for (i32 oi0 = 0; oi0 < n; oi0 += 64)
+	// The walk itself runs on a WINDOW of 64 consecutive back pointers held one per lane: a chain moves to
+	// smaller indices, mostly by a few elements at a time (runs of same-diagonal hits move by one), so one
+	// coalesced load serves dozens of hops that are then register reads (v_readlane) instead of dependent
+	// round trips to LDS (~100 cycles) or to memory (~1 us: the HiFi workload's 1500-hit groups spent 82 of
+	// 292 ms there).  Consumed entries are marked in the register and written back when the window moves.
+	i32 wbase = -0x40000000, win = -1;
+	bool dirty = false;
+	auto flushWin = [&]()
+	{
+		if (dirty)
+		{
+			if (wbase + lane < n) back[wbase + lane] = win;
+			wsort::wave_mem_fence();
+			dirty = false;
+		}
+	};
+	auto loadWin = [&](i32 pos)
+	{
+		flushWin();
+		wbase = max(0, pos - 63);
+		if (USE_LDS || (BT_CAP > 0 && n <= BT_CAP)) win = wbase + lane < n ? back[wbase + lane] : -1;
+		else win = wbase + lane < n ? __hip_atomic_load(&back[wbase + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+	};
+	const bool inMemory = !USE_LDS && !(BT_CAP > 0 && n <= BT_CAP);
+	// (LDS-resident groups keep the plain lane-0 walk below: their chains are short and jump further, the
+	// window reloads cost more than the LDS hops -- 9.9 against 7.4 ms on the bench workload)
+	for (i32 oi0 = 0; inMemory && oi0 < n; oi0 += 64)
+	{
+		flushWin();		// the screening below reads the array itself
+		const bool in = oi0 + lane < n;
+		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
+		i32 bk = -1;
+		if (in)
+		{
+			if (USE_LDS || (BT_CAP > 0 && n <= BT_CAP)) bk = back[st];
+			else bk = __hip_atomic_load(&back[st], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		u64 m = __builtin_amdgcn_ballot_w64(bk != -1);
+		while (m)
+		{
+			const int l = __ffsll((long long)m) - 1;
+			m &= m - 1;
+			const i32 start = __builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(l));
+			if (start < wbase || start >= wbase + 64) loadWin(start);
+			if (__builtin_amdgcn_readlane(win, __builtin_amdgcn_readfirstlane(start - wbase)) == -1) continue;	// consumed meanwhile
+			i32 firstM = 0, chainLength = 0, pos = start;
+			while (true)
+			{
+				if (pos < wbase || pos >= wbase + 64) loadWin(pos);
+				const int idx = __builtin_amdgcn_readfirstlane(pos - wbase);
+				const i32 np = __builtin_amdgcn_readlane(win, idx);
+				win = lane == idx ? -1 : win;
+				dirty = true;
+				firstM = pos;
+				++chainLength;
+				if (np == -1) break;
+				pos = np;
+			}
+			const i32 cb = (i32)cur[firstM], eb = (i32)ext[firstM];
+			const i32 ce = (i32)cur[start] + k - 1, ee = (i32)ext[start] + k - 1;
+			if (overlap_test(P, curId, extId, curLen, extLen, cb, ce, eb, ee))
+			{
+				const int4 c4 = make_int4(firstM, start, chainLength, score[start] - score[firstM] + k - 1);
+				if (lane == 0) cd[ncand] = c4;
+				if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
+				++ncand;
+			}
+		}
+	}
+	for (i32 oi0 = 0; !inMemory && oi0 < n; oi0 += 64)
 	{
 		const bool in = oi0 + lane < n;
 		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
@@ -594,6 +663,7 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 			}
 		}
 	}
+	wsort::wave_mem_fence();
 	if (lane != 0) return;
 	if (ncand == 0) return;
 	// candidates in descending score order as std::sort leaves them (overlap.cpp:432-434):

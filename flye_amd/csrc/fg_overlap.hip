@@ -745,11 +745,22 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	};
 	fetchCounts();
 	u32 nBig = cnt[0], nWide = cnt[2];
+	static const bool trace = getenv("FG_SORT_TRACE") != nullptr;
+	static const char* levelNames[32] = {
+		"k_sort_level#00", "k_sort_level#01", "k_sort_level#02", "k_sort_level#03", "k_sort_level#04", "k_sort_level#05",
+		"k_sort_level#06", "k_sort_level#07", "k_sort_level#08", "k_sort_level#09", "k_sort_level#10", "k_sort_level#11",
+		"k_sort_level#12", "k_sort_level#13", "k_sort_level#14", "k_sort_level#15", "k_sort_level#16", "k_sort_level#17",
+		"k_sort_level#18", "k_sort_level#19", "k_sort_level#20", "k_sort_level#21", "k_sort_level#22", "k_sort_level#23",
+		"k_sort_level#24", "k_sort_level#25", "k_sort_level#26", "k_sort_level#27", "k_sort_level#28", "k_sort_level#29",
+		"k_sort_level#30", "k_sort_level#31+"};
+	int level = 0;
 	while (nBig || nWide)
 	{
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p + 2, 0, 4, s));
-		ScopedK t(c->timer, "k_sort_level");
+		if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks\n", level, nBig, nWide);
+		ScopedK t(c->timer, trace ? levelNames[level < 31 ? level : 31] : "k_sort_level");
+		++level;
 		if (nWide)	// the long poles first
 			hipLaunchKernelGGL(k_sort_wide<KT>, nWide, SORT_WIDE_WAVES * 64, 0, s, wideA, nWide, dK, dV, c->dTmp32.p, nHits,
 							   kids + 2 * (size_t)nBig);
