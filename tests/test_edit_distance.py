@@ -128,3 +128,22 @@ def test_device_edit_distance_random_against_oracle(built):
     hw = [O.edit_distance(hpc(a), hpc(b)) for a, b in pairs]
     d, la, lb, kt = _device_distances(pairs, True)
     assert d.tolist() == hw and la.tolist() == [len(hpc(a)) for a, _ in pairs]
+
+
+@pytest.mark.gpu
+def test_device_edit_distance_long_pairs_many_strips(built):
+    """Repeat-stage sized substrings (disjointig against disjointig): dozens of 4096-row strips per pair, the
+    8-wave workgroup's strip pipeline (each wave a few hundred columns behind the strip above), band doubling
+    from 64 (no O(ND) attempt above 32 kb), unequal lengths; against the oracle's bit-vector form."""
+    from oracle import oracle as O
+    specs = [dict(seed=501, n=150_000, err=0.03), dict(seed=502, n=260_000, err=0.004, hp=500),
+             dict(seed=503, n=70_000, err=1.0, m=61_000), dict(seed=504, n=120_000, err=0.08, shift=9_000),
+             dict(seed=505, n=49_153, err=0.02), dict(seed=506, n=200_000, err=0.0)]
+    pairs = [edit_pair(s) for s in specs]
+    want = [O.edit_distance(a, b) for a, b in pairs]
+    d, la, lb, kt = _device_distances(pairs, False)
+    assert d.tolist() == want and la.tolist() == [len(a) for a, _ in pairs]
+    assert "k_edit_myers_wide" in kt
+    hw = [O.edit_distance(hpc(a), hpc(b)) for a, b in pairs]
+    d, la, lb, kt = _device_distances(pairs, True)
+    assert d.tolist() == hw
