@@ -1025,6 +1025,191 @@ int fo_edit_distance_k0(const uint8_t* a, int n, const uint8_t* b, int m, int k0
 	return editDistance(va, vb, k0);
 }
 
+// ---- banded affine-gap global alignment with CIGAR -----------------------------------
+// getAlignmentCigarKsw (reference src/sequence/alignment.cpp:102-216) = ksw_extz2_sse of minimap2 2.17
+// (reference lib/minimap2/ksw2_extz2_sse.c, built with sse2only=1, reference Makefile:21) with match 2,
+// mismatch -4, gap open 4, gap extend 2, band 64 doubling while the band cannot hold the length difference,
+// no z-drop, global backtrack (lib/minimap2/ksw2.h:116-152), then the CIGAR decoded into runs of '=', 'X',
+// 'I', 'D'.  The alignment PATH depends on the formulation's tie rules, on its 8-bit difference arithmetic
+// and on what the 16-byte-wide vector loop leaves in cells around the band, so the restatement below keeps
+// the same state -- five byte arrays u, v, x, y, s indexed by target position, the target and the reversed
+// query behind them in one zeroed buffer (the vector code's loads and stores run past array ends into the
+// neighbouring array, which this reproduces) -- and applies the per-cell byte operations of the "gap
+// left-alignment" loop, one anti-diagonal at a time.
+struct KswOut { bool zdropped = false; std::vector<uint32_t> cigar; };
+
+static inline uint8_t u8(int v) { return (uint8_t)v; }
+static inline int8_t s8(uint8_t v) { return (int8_t)v; }
+
+static KswOut kswExtz2Global(const uint8_t* query, int qlen, const uint8_t* target, int tlen, int8_t m, const int8_t* mat,
+							 int8_t q, int8_t e, int w)
+{
+	KswOut out;
+	if (m <= 0 || qlen <= 0 || tlen <= 0) return out;
+	const int qe = q + e;
+	const uint8_t qe2 = u8(qe * 2), maxSc = u8(mat[0] + qe * 2);
+	const int8_t scMch = mat[0], scMis = mat[1], scN = mat[m * m - 1] == 0 ? (int8_t)-e : mat[m * m - 1];
+	if (w < 0) w = std::max(tlen, qlen);
+	const int T16 = (tlen + 15) / 16 * 16, Q16 = (qlen + 15) / 16 * 16;
+	int nCol = std::min(qlen, tlen);
+	nCol = ((nCol < w + 1 ? nCol : w + 1) + 15) / 16 + 1;
+	int minSc = mat[1];
+	for (int t = 1; t < m * m; ++t) minSc = std::min<int>(minSc, mat[t]);
+	if (-minSc > 2 * qe) return out;
+	// one buffer, the vector code's layout: u | v | x | y | s | target | reversed query (+ 16 spare bytes)
+	std::vector<uint8_t> mem((size_t)T16 * 6 + Q16 + 32, 0);
+	uint8_t* U = mem.data(); uint8_t* V = U + T16; uint8_t* X = V + T16; uint8_t* Y = X + T16; uint8_t* S = Y + T16;
+	uint8_t* sf = S + T16; uint8_t* qr = sf + T16;
+	const size_t rowBytes = (size_t)nCol * 16;
+	std::vector<uint8_t> P((size_t)(qlen + tlen - 1) * rowBytes + 16, 0);
+	std::vector<int> off(qlen + tlen - 1), offEnd(qlen + tlen - 1);
+	for (int t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
+	memcpy(sf, target, tlen);
+	int lastSt = -1, lastEn = -1;
+	std::vector<uint8_t> nu, nv, nx, ny, nd;
+	for (int r = 0; r < qlen + tlen - 1; ++r)
+	{
+		int st = 0, en = tlen - 1;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < ((r - w + 1) >> 1)) st = (r - w + 1) >> 1;
+		if (en > ((r + w) >> 1)) en = (r + w) >> 1;
+		if (st > en) { out.zdropped = true; return out; }
+		const int st0 = st, en0 = en;
+		st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+		uint8_t x1, v1;
+		if (st > 0)
+		{
+			if (st - 1 >= lastSt && st - 1 <= lastEn) { x1 = X[st - 1]; v1 = V[st - 1]; }
+			else x1 = v1 = 0;
+		}
+		else { x1 = 0; v1 = r ? u8(q) : 0; }
+		if (en >= r) { Y[r] = 0; U[r] = r ? u8(q) : 0; }
+		// scores of the diagonal, in 16-byte pieces from st0 (pieces may run past en0 and past the array)
+		const uint8_t* qrr = qr + (qlen - 1 - r);
+		for (int t = st0; t <= en0; t += 16)
+		{
+			uint8_t tmp[16];
+			for (int b = 0; b < 16; ++b)
+			{
+				const uint8_t sq = sf[t + b], sb = qrr[t + b];
+				const bool wild = sq == u8(m - 1) || sb == u8(m - 1);
+				tmp[b] = u8(wild ? scN : (sq == sb ? scMch : scMis));
+			}
+			memcpy(S + t, tmp, 16);
+		}
+		// every cell of [st, en] from the previous diagonal's state
+		const int nCell = en - st + 1;
+		nu.assign(nCell, 0); nv.assign(nCell, 0); nx.assign(nCell, 0); ny.assign(nCell, 0); nd.assign(nCell, 0);
+		for (int t = st; t <= en; ++t)
+		{
+			const uint8_t xt1 = t == st ? x1 : X[t - 1], vt1 = t == st ? v1 : V[t - 1];
+			const uint8_t ut = U[t];
+			uint8_t z = u8(S[t] + qe2);
+			const uint8_t a = u8(xt1 + vt1), b = u8(Y[t] + ut);
+			uint8_t d = s8(a) > s8(z) ? 1 : 0;
+			z = s8(z) > 0 ? z : 0;
+			z = std::max(z, a);
+			if (s8(b) > s8(z)) d = 2;
+			z = std::max(z, b);
+			z = std::min(z, maxSc);
+			nu[t - st] = u8(z - vt1);
+			nv[t - st] = u8(z - ut);
+			const uint8_t zq = u8(z - q);
+			const uint8_t a2 = u8(a - zq), b2 = u8(b - zq);
+			if (s8(a2) > 0) { nx[t - st] = a2; d |= 0x08; }
+			if (s8(b2) > 0) { ny[t - st] = b2; d |= 0x10; }
+			nd[t - st] = d;
+		}
+		memcpy(U + st, nu.data(), nCell); memcpy(V + st, nv.data(), nCell);
+		memcpy(X + st, nx.data(), nCell); memcpy(Y + st, ny.data(), nCell);
+		memcpy(P.data() + (size_t)r * rowBytes, nd.data(), std::min<size_t>(nCell, rowBytes));
+		off[r] = st; offEnd[r] = en;
+		lastSt = st; lastEn = en;
+	}
+	// backtrack from (tlen - 1, qlen - 1) (ksw2.h:116-152, rotated matrix, no introns)
+	std::vector<uint32_t> cig;
+	auto push = [&](uint32_t op, int len)
+	{
+		if (cig.empty() || op != (cig.back() & 0xf)) cig.push_back((uint32_t)len << 4 | op);
+		else cig.back() += (uint32_t)len << 4;
+	};
+	int i = tlen - 1, j = qlen - 1, state = 0;
+	while (i >= 0 && j >= 0)
+	{
+		const int r = i + j;
+		int force = -1;
+		if (i < off[r]) force = 2;
+		if (i > offEnd[r]) force = 1;
+		const uint32_t tmp = force < 0 ? P[(size_t)r * rowBytes + i - off[r]] : 0;
+		if (state == 0) state = tmp & 7;
+		else if (!((tmp >> (state + 2)) & 1)) state = 0;
+		if (state == 0) state = tmp & 7;
+		if (force >= 0) state = force;
+		if (state == 0) { push(0, 1); --i; --j; }
+		else if (state == 1 || state == 3) { push(2, 1); --i; }
+		else { push(1, 1); --j; }
+	}
+	if (i >= 0) push(2, i + 1);
+	if (j >= 0) push(1, j + 1);
+	std::reverse(cig.begin(), cig.end());
+	out.cigar.swap(cig);
+	return out;
+}
+
+struct CigRun { char op; int32_t len; };
+
+// getAlignmentCigarKsw: band doubling, decode; returns the error rate (alignment.cpp:102-216)
+static float alignmentCigarKsw(const std::vector<uint8_t>& trg, const std::vector<uint8_t>& qry, std::vector<CigRun>& cigarOut)
+{
+	const int8_t a = 2, b = -4;
+	const int8_t subsMat[] = {a, b, b, b, 0,  b, a, b, b, 0,  b, b, a, b, 0,  b, b, b, a, 0,  0, 0, 0, 0, 0};
+	KswOut ez;
+	int bandWidth = 64;
+	for (;;)
+	{
+		ez = kswExtz2Global(qry.data(), (int)qry.size(), trg.data(), (int)trg.size(), 5, subsMat, 4, 2, bandWidth);
+		if (!ez.zdropped) break;
+		if (bandWidth > (int)std::max(qry.size(), trg.size())) break;
+		bandWidth *= 2;
+	}
+	int numMiss = 0, numIndels = 0;
+	cigarOut.clear();
+	size_t posQry = 0, posTrg = 0;
+	for (uint32_t c : ez.cigar)
+	{
+		const int size = (int)(c >> 4);
+		const char op = "MID"[c & 0xf];
+		if (op == 'M')
+		{
+			for (int t = 0; t < size; ++t)
+			{
+				const char match = trg[posTrg + t] == qry[posQry + t] ? '=' : 'X';
+				if (t == 0 || match != cigarOut.back().op) cigarOut.push_back({match, 1});
+				else ++cigarOut.back().len;
+				numMiss += match == 'X';
+			}
+			posQry += size; posTrg += size;
+		}
+		else if (op == 'I') { cigarOut.push_back({'I', size}); posQry += size; numIndels += size; }
+		else { cigarOut.push_back({'D', size}); posTrg += size; numIndels += size; }
+	}
+	return float(numMiss + numIndels) / std::max(trg.size(), qry.size());
+}
+
+extern "C" {
+// decoded CIGAR of getAlignmentCigarKsw(trg, qry) as (op, len) pairs; returns the number of runs (writes at most cap)
+int64_t fo_ksw_cigar(const uint8_t* trg, int tlen, const uint8_t* qry, int qlen, uint8_t* ops, int32_t* lens, int64_t cap, float* errRate)
+{
+	std::vector<uint8_t> t(trg, trg + tlen), q(qry, qry + qlen);
+	std::vector<CigRun> c;
+	const float er = alignmentCigarKsw(t, q, c);
+	if (errRate) *errRate = er;
+	for (size_t i = 0; i < c.size() && (int64_t)i < cap; ++i) { ops[i] = (uint8_t)c[i].op; lens[i] = c[i].len; }
+	return (int64_t)c.size();
+}
+} // extern "C"
+
 // ---- introsort emulation self-test against the real std::sort ---------------
 struct KV { u64 key; u32 val; };
 struct KVAcc {

@@ -90,6 +90,9 @@ def lib():
         L.fo_edit_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.fo_edit_distance_dp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.fo_edit_distance_k0.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.fo_ksw_cigar.restype = C.c_int64
+        L.fo_ksw_cigar.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.POINTER(C.c_float)]
         L.fo_introsort_mismatches.restype = C.c_int64
         L.fo_introsort_mismatches.argtypes = [C.c_void_p, C.c_int64]
         L.fo_std_sort_perm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
@@ -300,6 +303,38 @@ def ref_edlib_distances(pairs):
     finally:
         os.unlink(path)
     return [int(x) for x in out.stdout.split()]
+
+
+def ksw_cigar(trg: np.ndarray, qry: np.ndarray):
+    """getAlignmentCigarKsw(trg, qry) (alignment.cpp:102-216) by the oracle's restatement of ksw_extz2:
+    (error-rate bit pattern as hex, CIGAR text "<len><op> ...")."""
+    t = np.ascontiguousarray(trg, np.uint8)
+    q = np.ascontiguousarray(qry, np.uint8)
+    cap = len(t) + len(q) + 8
+    ops = np.empty(cap, np.uint8)
+    lens = np.empty(cap, np.int32)
+    err = C.c_float()
+    n = lib().fo_ksw_cigar(t.ctypes.data, len(t), q.ctypes.data, len(q), ops.ctypes.data, lens.ctypes.data, cap, C.byref(err))
+    bits = int(np.array([err.value], np.float32).view(np.uint32)[0])
+    return f"{bits:08x}", " ".join(f"{int(lens[i])}{chr(ops[i])}" for i in range(n))
+
+
+def ref_ksw_cigars(pairs):
+    """The same through the REFERENCE's getAlignmentCigarKsw (oracle/_ref/ref_dumper --ksw-pairs)."""
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for a, b in pairs:
+            f.write("^" + "".join("ACGT"[x] for x in a) + " ^" + "".join("ACGT"[x] for x in b) + "\n")
+        path = f.name
+    try:
+        out = subprocess.run([REF_DUMPER, "--ksw-pairs", path], check=True, capture_output=True, text=True)
+    finally:
+        os.unlink(path)
+    res = []
+    for line in out.stdout.splitlines():
+        t = line.split(" ", 1)
+        res.append((t[0], t[1] if len(t) > 1 else ""))
+    return res
 
 
 def introsort_mismatches(keys: np.ndarray) -> int:

@@ -45,6 +45,7 @@
 #include "common/config.h"
 #include "common/parallel.h"
 #include "sequence/edlib.h"
+#include "sequence/alignment.h"
 #undef private
 #undef protected
 
@@ -86,6 +87,26 @@ int main(int argc, char** argv)
 		else if (a == "--keep-aln") keepAln = atoi(next().c_str());
 		else if (a == "--partition-bad") partitionBad = atoi(next().c_str());
 		else if (a == "--max-div") maxDiv = strtof(next().c_str(), nullptr);
+		else if (a == "--ksw-pairs")
+		{
+			// kernel-level pin of the banded affine-gap alignment: every line holds a target
+			// and a query string ('^' in front); prints what the reference's getAlignmentCigarKsw
+			// (alignment.cpp:102-216: ksw_extz2_sse, band 64 doubling, global backtrack, decoded CIGAR)
+			// returns: the error rate's bit pattern and the CIGAR runs
+			std::ifstream in(next());
+			std::string qa, qb;
+			while (in >> qa >> qb)
+			{
+				qa.erase(0, 1); qb.erase(0, 1);
+				DnaSequence trg(qa), qry(qb);
+				std::vector<CigOp> cigar;
+				float err = getAlignmentCigarKsw(trg, 0, trg.length(), qry, 0, qry.length(), 1.0f, cigar);
+				printf("%08x", fbits(err));
+				for (auto& c : cigar) printf(" %d%c", c.len, c.op);
+				printf("\n");
+			}
+			return 0;
+		}
 		else if (a == "--edlib-pairs")
 		{
 			// kernel-level pin of the edit-distance restatements: every line of the file holds two

@@ -147,3 +147,45 @@ def test_device_edit_distance_long_pairs_many_strips(built):
     hw = [O.edit_distance(hpc(a), hpc(b)) for a, b in pairs]
     d, la, lb, kt = _device_distances(pairs, True)
     assert d.tolist() == hw
+
+
+# ---- banded affine-gap alignment with CIGAR (getAlignmentCigarKsw, alignment.cpp:102-216) ----------
+def _ksw_golden():
+    with open(os.path.join(GOLDEN, "ksw_pairs.json")) as f:
+        return json.load(f)
+
+
+def _ksw_check(got, g):
+    import hashlib
+    bits, cig = got
+    assert bits == g["err_bits"], g["spec"]
+    assert hashlib.sha256(cig.encode()).hexdigest() == g["cigar_sha256"], g["spec"]
+    if "cigar" in g:
+        assert cig == g["cigar"]
+
+
+def test_oracle_ksw_cigar_equals_reference(built):
+    """The oracle's restatement of ksw_extz2 (same byte state as the vector code, incl. what it leaves around
+    the band and past array ends) against the reference's getAlignmentCigarKsw: error-rate bits and CIGAR."""
+    from oracle import oracle as O
+    for g in _ksw_golden():
+        a, b = edit_pair(g["spec"])
+        assert (len(a), len(b)) == (g["tlen"], g["qlen"])
+        _ksw_check(O.ksw_cigar(a, b), g)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_dumper")),
+                    reason="oracle/_ref/ref_dumper not built")
+def test_oracle_ksw_cigar_live_against_reference(built):
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    pairs = []
+    for _ in range(150):
+        small = rng.integers(0, 2) == 0
+        n = int(rng.integers(1, 90 if small else 2500))
+        spec = dict(seed=int(rng.integers(1, 1 << 30)), n=n, err=float(rng.choice([0.0, 0.02, 0.15, 1.0])),
+                    m=int(rng.integers(1, 90 if small else 2500)), hp=int(rng.integers(0, 20)))
+        a, b = edit_pair(spec)
+        if len(a) and len(b):
+            pairs.append((a, b))
+    assert [O.ksw_cigar(a, b) for a, b in pairs] == O.ref_ksw_cigars(pairs)
