@@ -375,6 +375,79 @@ int fg_debug_edit_distances(fg_ctx* c, uint32_t n_pairs, int use_hpc, int32_t* o
 	});
 }
 
+namespace {
+struct CigarOwner {
+	std::vector<uint64_t> runOff;
+	std::vector<uint8_t> ops;
+	std::vector<int32_t> lens;
+	std::vector<float> err;
+};
+}
+
+int fg_align_cigar_ksw(fg_ctx* c, uint32_t n_pairs, const uint8_t* trg, const uint64_t* trg_off, const uint8_t* qry,
+					   const uint64_t* qry_off, struct fg_cigar_batch* out)
+{
+	if (!c || !out || !trg_off || !qry_off || (trg_off[n_pairs] && !trg) || (qry_off[n_pairs] && !qry)) return FG_ERR_ARG;
+	memset(out, 0, sizeof(*out));
+	CigarOwner* own = nullptr;
+	const int rc = guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		std::vector<u64> runOff;
+		std::vector<u32> runs;
+		fgKswAlign(c, n_pairs, trg, trg_off, qry, qry_off, runOff, runs);
+		own = new CigarOwner;
+		own->runOff.assign(n_pairs + 1, 0);
+		own->err.assign(n_pairs, 0.0f);
+		// the decoding loop of alignment.cpp:172-211, on the host: M runs split into '=' / 'X'
+		for (u32 i = 0; i < n_pairs; ++i)
+		{
+			const uint8_t* t = trg + trg_off[i];
+			const uint8_t* q = qry + qry_off[i];
+			const size_t trgLen = trg_off[i + 1] - trg_off[i], qryLen = qry_off[i + 1] - qry_off[i];
+			size_t posQry = 0, posTrg = 0;
+			int numMiss = 0, numIndels = 0;
+			const size_t first = own->ops.size();
+			for (u64 k = runOff[i]; k < runOff[i + 1]; ++k)
+			{
+				const int size = (int)(runs[k] >> 4);
+				const u32 op = runs[k] & 0xf;
+				if (op == 0)
+				{
+					for (int x = 0; x < size; ++x)
+					{
+						const char match = t[posTrg + x] == q[posQry + x] ? '=' : 'X';
+						if (x == 0 || match != (char)own->ops.back()) { own->ops.push_back((uint8_t)match); own->lens.push_back(1); }
+						else ++own->lens.back();
+						numMiss += match == 'X';
+					}
+					posQry += size; posTrg += size;
+				}
+				else if (op == 1) { own->ops.push_back('I'); own->lens.push_back(size); posQry += size; numIndels += size; }
+				else { own->ops.push_back('D'); own->lens.push_back(size); posTrg += size; numIndels += size; }
+			}
+			(void)first;
+			own->runOff[i + 1] = own->ops.size();
+			own->err[i] = float(numMiss + numIndels) / std::max(trgLen, qryLen);
+		}
+	});
+	if (rc != FG_OK) { delete own; return rc; }
+	out->n_pairs = n_pairs;
+	out->run_off = own->runOff.data();
+	out->ops = own->ops.data();
+	out->lens = own->lens.data();
+	out->err_rate = own->err.data();
+	out->owner_ = own;
+	return FG_OK;
+}
+
+void fg_release_cigars(struct fg_cigar_batch* b)
+{
+	if (!b) return;
+	delete (CigarOwner*)b->owner_;
+	memset(b, 0, sizeof(*b));
+}
+
 void fg_release_batch(struct fg_overlap_batch* b)
 {
 	if (!b) return;

@@ -531,6 +531,8 @@ void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64
 void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);
+void fgKswAlign(fg_ctx* c, u32 nPairs, const uint8_t* trg, const u64* trgOff, const uint8_t* qry, const u64* qryOff,
+				std::vector<u64>& runOff, std::vector<u32>& runs);
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg);
 void fgDebugEditDistances(fg_ctx* c, u32 nPairs, int useHpc, i32* outDist, i32* outLenA, i32* outLenB);
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,

@@ -38,7 +38,7 @@ ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_l
                "fg_container_info", "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_index_begin_solid", "fg_index_begin_minimizers", "fg_index_build_range", "fg_index_finish",
                "fg_import_index", "fg_index_device_arrays", "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
-               "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances"]
+               "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances", "fg_align_cigar_ksw", "fg_release_cigars"]
 
 
 class FlyeGpuError(RuntimeError):
@@ -72,6 +72,11 @@ class OverlapBatch(C.Structure):
                 ("matches", C.c_void_p), ("needs_trim", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
                 ("seed_hits", C.c_uint64), ("dp_groups", C.c_uint64), ("dp_elements", C.c_uint64),
                 ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
+
+
+class CigarBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint32), ("run_off", C.POINTER(C.c_uint64)), ("ops", C.POINTER(C.c_uint8)),
+                ("lens", C.POINTER(C.c_int32)), ("err_rate", C.POINTER(C.c_float)), ("owner_", C.c_void_p)]
 
 
 class BridgeStats(C.Structure):
@@ -122,6 +127,9 @@ def load_library():
         L.fg_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int]
         L.fg_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.fg_debug_edit_distances.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fg_align_cigar_ksw.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(CigarBatch)]
+        L.fg_release_cigars.argtypes = [C.POINTER(CigarBatch)]
         # include/flye_gpu_bridge.h
         L.fgb_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(DetectorParams), C.c_uint32, C.c_uint32]
         L.fgb_destroy.argtypes = [C.c_void_p]
@@ -287,6 +295,29 @@ class Context:
         self._check(self.L.fg_debug_edit_distances(self.h, n_pairs, int(bool(use_hpc)), d.ctypes.data,
                                                    la.ctypes.data, lb.ctypes.data))
         return d, la, lb
+
+    def align_cigar_ksw(self, pairs):
+        """getAlignmentCigarKsw (alignment.cpp:102-216) of (target, query) pairs of 0..3 arrays on the device:
+        list of (error-rate bit pattern as hex, CIGAR text "<len><op> ...")."""
+        n = len(pairs)
+        trg = np.concatenate([np.asarray(a, np.uint8) for a, _ in pairs]) if n else np.empty(0, np.uint8)
+        qry = np.concatenate([np.asarray(b, np.uint8) for _, b in pairs]) if n else np.empty(0, np.uint8)
+        toff = np.zeros(n + 1, np.uint64)
+        qoff = np.zeros(n + 1, np.uint64)
+        toff[1:] = np.cumsum([len(a) for a, _ in pairs])
+        qoff[1:] = np.cumsum([len(b) for _, b in pairs])
+        trg = np.ascontiguousarray(trg if len(trg) else np.zeros(1, np.uint8))
+        qry = np.ascontiguousarray(qry if len(qry) else np.zeros(1, np.uint8))
+        b = CigarBatch()
+        self._check(self.L.fg_align_cigar_ksw(self.h, n, trg.ctypes.data, toff.ctypes.data, qry.ctypes.data,
+                                              qoff.ctypes.data, C.byref(b)))
+        out = []
+        for i in range(n):
+            a0, a1 = int(b.run_off[i]), int(b.run_off[i + 1])
+            bits = int(np.array([b.err_rate[i]], np.float32).view(np.uint32)[0])
+            out.append((f"{bits:08x}", " ".join(f"{b.lens[k]}{chr(b.ops[k])}" for k in range(a0, a1))))
+        self.L.fg_release_cigars(C.byref(b))
+        return out
 
     def kernel_times(self):
         arr = (KernelTime * 64)()

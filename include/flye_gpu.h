@@ -244,6 +244,25 @@ int fg_debug_sort_pairs(fg_ctx* ctx, uint64_t* keys, uint32_t* vals,
 int fg_debug_edit_distances(fg_ctx* ctx, uint32_t n_pairs, int use_hpc, int32_t* out_dist,
                             int32_t* out_len_a, int32_t* out_len_b);
 
+/* getAlignmentCigarKsw (src/sequence/alignment.cpp:102-216) for a batch of (target, query)
+ * string pairs: banded affine-gap global alignment (ksw_extz2 of the reference's lib/minimap2 with match 2,
+ * mismatch -4, gap open 4, gap extend 2; band 64 doubling while too narrow; global backtrack) with the CIGAR
+ * decoded into runs of '=', 'X', 'I', 'D' and the error rate (mismatches + indel bases) / max(length).
+ * trg / qry: one byte per base (0..3), pair i at [off[i], off[i + 1]).  The DP and the backtrack run on the
+ * device; the decoding of the M runs and the float on the host.  Runs of pair i: ops / lens[run_off[i] ..
+ * run_off[i + 1]). */
+struct fg_cigar_batch {
+	uint32_t  n_pairs;
+	uint64_t* run_off;
+	uint8_t*  ops;        /* '=', 'X', 'I', 'D' */
+	int32_t*  lens;
+	float*    err_rate;   /* n_pairs */
+	void*     owner_;
+};
+int fg_align_cigar_ksw(fg_ctx* ctx, uint32_t n_pairs, const uint8_t* trg, const uint64_t* trg_off,
+                       const uint8_t* qry, const uint64_t* qry_off, struct fg_cigar_batch* out);
+void fg_release_cigars(struct fg_cigar_batch* b);
+
 #ifdef __cplusplus
 }
 #endif

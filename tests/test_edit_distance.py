@@ -189,3 +189,41 @@ def test_oracle_ksw_cigar_live_against_reference(built):
         if len(a) and len(b):
             pairs.append((a, b))
     assert [O.ksw_cigar(a, b) for a, b in pairs] == O.ref_ksw_cigars(pairs)
+
+
+@pytest.mark.gpu
+def test_device_ksw_cigar_equals_reference(built):
+    """fg_align_cigar_ksw (the DP + backtrack on the device, decoding on the host) against what the reference's
+    getAlignmentCigarKsw returned for the fixture pairs."""
+    from flye_amd import gpu
+    gold = _ksw_golden()
+    pairs = [edit_pair(g["spec"]) for g in gold]
+    ctx = gpu.Context(17, 0)
+    got = ctx.align_cigar_ksw(pairs)
+    for g, x in zip(gold, got):
+        _ksw_check(x, g)
+    assert "k_ksw_extz2" in ctx.kernel_times()
+
+
+@pytest.mark.gpu
+def test_device_ksw_cigar_random_against_oracle(built, monkeypatch):
+    from flye_amd import gpu
+    from oracle import oracle as O
+    rng = np.random.default_rng(33)
+    pairs = []
+    for _ in range(500):
+        small = rng.integers(0, 3) == 0
+        n = int(rng.integers(1, 100 if small else 4000))
+        spec = dict(seed=int(rng.integers(1, 1 << 30)), n=n, err=float(rng.choice([0.0, 0.01, 0.08, 0.25, 1.0])),
+                    m=int(rng.integers(1, 100 if small else 4000)), hp=int(rng.integers(0, 30)))
+        if rng.integers(0, 4) == 0 and spec["err"] < 1:
+            spec["shift"] = int(rng.integers(0, min(n, 400)))
+        a, b = edit_pair(spec)
+        if len(a) and len(b):
+            pairs.append((a, b))
+    want = [O.ksw_cigar(a, b) for a, b in pairs]
+    ctx = gpu.Context(17, 0)
+    assert ctx.align_cigar_ksw(pairs) == want
+    # the same in several scratch-bounded sub-batches
+    monkeypatch.setenv("FG_KSW_SCRATCH_BYTES", str(40 << 20))
+    assert ctx.align_cigar_ksw(pairs) == want
