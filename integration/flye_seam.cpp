@@ -9,6 +9,9 @@
 //   OverlapDetector::getSeqOverlaps
 //       (src/sequence/overlap.cpp:99-508)                   -> fgb_quick_ex (the batch scheduler:
 //       Flye's worker threads call this one read at a time, include/flye_gpu_bridge.h)
+//   getAlignmentCigarKsw
+//       (src/sequence/alignment.cpp:102-216)                -> fg_align_cigar_ksw (ksw2's banded
+//       affine-gap alignment with CIGAR on the device)
 //
 // Everything above the seams stays reference code, compiled from the reference's files:
 // OverlapContainer::quickSeqOverlaps / lazySeqOverlaps (cache + complemented twin),
@@ -187,6 +190,82 @@ void VertexIndex::clear()
 	}
 }
 
+// ---- seam 3: getAlignmentCigarKsw ------------------------------------------------------
+// alignment.cpp:102-216: banded affine-gap global alignment with CIGAR, called by checkIdyAndTrim (:306-495, on
+// the records getSeqOverlaps marks for trimming) and by the consensus stage.  checkIdyAndTrim itself -- the
+// interval search over the CIGAR, its std::sort, the coordinate mapping through the compression tables --
+// stays the reference's compiled code and reaches this definition through the symbol.
+namespace {
+std::mutex g_alnMu;
+fg_ctx* g_alnCtx = nullptr;		// alignments need no reads and no index: one context for the process
+
+struct AlnResult { std::vector<uint8_t> trg, qry; std::vector<CigOp> cigar; float errRate; };
+// alignments computed ahead for the calling thread (getSeqOverlaps knows all records of a read that will be
+// trimmed and sends them to the device as ONE batch; checkIdyAndTrim then asks for them one by one)
+thread_local std::vector<AlnResult> t_ahead;
+
+void alignBatch(std::vector<AlnResult>& jobs)
+{
+	if (jobs.empty()) return;
+	std::vector<uint8_t> trg, qry;
+	std::vector<uint64_t> toff(1, 0), qoff(1, 0);
+	for (auto& j : jobs)
+	{
+		trg.insert(trg.end(), j.trg.begin(), j.trg.end()); toff.push_back(trg.size());
+		qry.insert(qry.end(), j.qry.begin(), j.qry.end()); qoff.push_back(qry.size());
+	}
+	if (trg.empty()) trg.push_back(0);
+	if (qry.empty()) qry.push_back(0);
+	fg_cigar_batch b;
+	{
+		std::lock_guard<std::mutex> g(g_alnMu);
+		if (!g_alnCtx)
+		{
+			const int device = getenv("FLYE_GPU_DEVICE") ? atoi(getenv("FLYE_GPU_DEVICE")) : 0;
+			check(fg_create(&g_alnCtx, device, (int)Parameters::get().kmerSize), nullptr, "fg_create");
+		}
+		check(fg_align_cigar_ksw(g_alnCtx, (uint32_t)jobs.size(), trg.data(), toff.data(), qry.data(), qoff.data(), &b),
+			  g_alnCtx, "fg_align_cigar_ksw");
+	}
+	for (size_t i = 0; i < jobs.size(); ++i)
+	{
+		jobs[i].cigar.clear();
+		for (uint64_t k = b.run_off[i]; k < b.run_off[i + 1]; ++k) jobs[i].cigar.push_back({(char)b.ops[k], (int)b.lens[k]});
+		jobs[i].errRate = b.err_rate[i];
+	}
+	fg_release_cigars(&b);
+}
+
+// homopolymerCompression's sequence (alignment.cpp:52-70) as bytes
+void compressedBytes(const DnaSequence& seq, int32_t start, int32_t length, bool doCompression, std::vector<uint8_t>& out)
+{
+	out.clear();
+	for (int32_t i = 0; i < length; ++i)
+	{
+		const uint8_t b = (uint8_t)seq.atRaw((size_t)i + start);
+		if (!doCompression || i == 0 || out.back() != b) out.push_back(b);
+	}
+}
+} // namespace
+
+float getAlignmentCigarKsw(const DnaSequence& trgSeq, size_t trgBegin, size_t trgLen,
+						   const DnaSequence& qrySeq, size_t qryBegin, size_t qryLen,
+						   float maxAlnErr, std::vector<CigOp>& cigarOut)
+{
+	(void)maxAlnErr;
+	AlnResult one;
+	one.trg.resize(trgLen); one.qry.resize(qryLen);
+	for (size_t i = 0; i < trgLen; ++i) one.trg[i] = (uint8_t)trgSeq.atRaw(i + trgBegin);
+	for (size_t i = 0; i < qryLen; ++i) one.qry[i] = (uint8_t)qrySeq.atRaw(i + qryBegin);
+	for (auto& r : t_ahead)
+		if (r.trg == one.trg && r.qry == one.qry) { cigarOut = r.cigar; return r.errRate; }
+	std::vector<AlnResult> jobs(1);
+	jobs[0].trg.swap(one.trg); jobs[0].qry.swap(one.qry);
+	alignBatch(jobs);
+	cigarOut = jobs[0].cigar;
+	return jobs[0].errRate;
+}
+
 // ---- seam 2: OverlapDetector::getSeqOverlaps ---------------------------------------------------------
 std::vector<OverlapRange>
 OverlapDetector::getSeqOverlaps(const FastaRecord& fastaRec, bool forceLocal, OvlpDivStats& divStats, int maxOverlaps) const
@@ -233,6 +312,21 @@ OverlapDetector::getSeqOverlaps(const FastaRecord& fastaRec, bool forceLocal, Ov
 
 	std::vector<OverlapRange> detectedOverlaps;
 	detectedOverlaps.reserve(res.n);
+	// every record of this read that checkIdyAndTrim will realign: one device batch ahead of the calls
+	t_ahead.clear();
+	if (res.needs_trim)
+	{
+		for (uint64_t i = 0; i < res.n; ++i)
+			if (res.needs_trim[i])
+			{
+				const fg_overlap_rec& r = res.recs[i];
+				t_ahead.emplace_back();
+				compressedBytes(fastaRec.sequence, r.cur_begin, r.cur_end - r.cur_begin, _useHpc, t_ahead.back().trg);
+				compressedBytes(_seqContainer.getSeq(FastaRecord::Id(r.ext_id)), r.ext_begin, r.ext_end - r.ext_begin, _useHpc,
+								t_ahead.back().qry);
+			}
+		alignBatch(t_ahead);
+	}
 	for (uint64_t i = 0; i < res.n; ++i)
 	{
 		const fg_overlap_rec& r = res.recs[i];
@@ -256,6 +350,7 @@ OverlapDetector::getSeqOverlaps(const FastaRecord& fastaRec, bool forceLocal, Ov
 		else detectedOverlaps.push_back(ovlp);
 	}
 	for (uint64_t i = 0; i < res.n_div_stats; ++i) divStats.add(res.div_stats[i]);	// overlap.cpp:500-506
+	t_ahead.clear();
 	fgb_release_result(&res);
 	return detectedOverlaps;
 }
