@@ -2,6 +2,7 @@
 // build/export entry points and the error boundary.  No exception leaves this
 // file; there is no CPU fallback -- without a HIP device fg_create fails.
 #include "fg_ctx.h"
+#include <chrono>
 
 #include <algorithm>
 #include <new>
@@ -396,40 +397,74 @@ int fg_align_cigar_ksw(fg_ctx* c, uint32_t n_pairs, const uint8_t* trg, const ui
 		std::vector<u64> runOff;
 		std::vector<u32> runs;
 		fgKswAlign(c, n_pairs, trg, trg_off, qry, qry_off, runOff, runs);
+		const auto tDec = std::chrono::steady_clock::now();
 		own = new CigarOwner;
 		own->runOff.assign(n_pairs + 1, 0);
 		own->err.assign(n_pairs, 0.0f);
-		// the decoding loop of alignment.cpp:172-211, on the host: M runs split into '=' / 'X'
-		for (u32 i = 0; i < n_pairs; ++i)
+		// the decoding loop of alignment.cpp:172-211, on the host: M runs split into '=' / 'X'.  Pairs are
+		// independent: slices of the batch (cut by bases) go to the context's worker threads.
+		u64 totalBp = 0;
+		for (u32 i = 0; i < n_pairs; ++i) totalBp += (trg_off[i + 1] - trg_off[i]) + (qry_off[i + 1] - qry_off[i]);
+		unsigned nThreads = totalBp < (1u << 20) ? 1u : std::max(1u, std::min(fg_usable_cpus(), 32u));
+		if (getenv("FG_SHIM_THREADS")) nThreads = std::max(1, atoi(getenv("FG_SHIM_THREADS")));
+		std::vector<u32> cut(nThreads + 1, n_pairs);
+		cut[0] = 0;
 		{
-			const uint8_t* t = trg + trg_off[i];
-			const uint8_t* q = qry + qry_off[i];
-			const size_t trgLen = trg_off[i + 1] - trg_off[i], qryLen = qry_off[i + 1] - qry_off[i];
-			size_t posQry = 0, posTrg = 0;
-			int numMiss = 0, numIndels = 0;
-			const size_t first = own->ops.size();
-			for (u64 k = runOff[i]; k < runOff[i + 1]; ++k)
+			u64 acc = 0; unsigned t = 1;
+			for (u32 i = 0; i < n_pairs && t < nThreads; ++i)
 			{
-				const int size = (int)(runs[k] >> 4);
-				const u32 op = runs[k] & 0xf;
-				if (op == 0)
-				{
-					for (int x = 0; x < size; ++x)
-					{
-						const char match = t[posTrg + x] == q[posQry + x] ? '=' : 'X';
-						if (x == 0 || match != (char)own->ops.back()) { own->ops.push_back((uint8_t)match); own->lens.push_back(1); }
-						else ++own->lens.back();
-						numMiss += match == 'X';
-					}
-					posQry += size; posTrg += size;
-				}
-				else if (op == 1) { own->ops.push_back('I'); own->lens.push_back(size); posQry += size; numIndels += size; }
-				else { own->ops.push_back('D'); own->lens.push_back(size); posTrg += size; numIndels += size; }
+				acc += (trg_off[i + 1] - trg_off[i]) + (qry_off[i + 1] - qry_off[i]);
+				while (t < nThreads && acc >= totalBp * t / nThreads) cut[t++] = i + 1;
 			}
-			(void)first;
-			own->runOff[i + 1] = own->ops.size();
-			own->err[i] = float(numMiss + numIndels) / std::max(trgLen, qryLen);
 		}
+		std::vector<std::vector<uint8_t>> tOps(nThreads);
+		std::vector<std::vector<int32_t>> tLens(nThreads);
+		c->shimPool.run(nThreads, [&](unsigned th)
+		{
+			// thread-local vectors (the headers of tOps[] sit next to each other: appending through them would
+			// bounce one cache line between all threads), handed over at the end
+			std::vector<uint8_t> ops;
+			std::vector<int32_t> lens;
+			for (u32 i = cut[th]; i < cut[th + 1]; ++i)
+			{
+				const uint8_t* t = trg + trg_off[i];
+				const uint8_t* q = qry + qry_off[i];
+				const size_t trgLen = trg_off[i + 1] - trg_off[i], qryLen = qry_off[i + 1] - qry_off[i];
+				size_t posQry = 0, posTrg = 0;
+				int numMiss = 0, numIndels = 0;
+				const size_t first = ops.size();
+				for (u64 k = runOff[i]; k < runOff[i + 1]; ++k)
+				{
+					const int size = (int)(runs[k] >> 4);
+					const u32 op = runs[k] & 0xf;
+					if (op == 0)
+					{
+						for (int x = 0; x < size; ++x)
+						{
+							const char match = t[posTrg + x] == q[posQry + x] ? '=' : 'X';
+							if (x == 0 || match != (char)ops.back()) { ops.push_back((uint8_t)match); lens.push_back(1); }
+							else ++lens.back();
+							numMiss += match == 'X';
+						}
+						posQry += size; posTrg += size;
+					}
+					else if (op == 1) { ops.push_back('I'); lens.push_back(size); posQry += size; numIndels += size; }
+					else { ops.push_back('D'); lens.push_back(size); posTrg += size; numIndels += size; }
+				}
+				own->runOff[i + 1] = ops.size() - first;		// count; summed below
+				own->err[i] = float(numMiss + numIndels) / std::max(trgLen, qryLen);
+			}
+			tOps[th].swap(ops); tLens[th].swap(lens);
+		});
+		for (u32 i = 0; i < n_pairs; ++i) own->runOff[i + 1] += own->runOff[i];
+		own->ops.reserve(own->runOff[n_pairs]); own->lens.reserve(own->runOff[n_pairs]);
+		for (unsigned th = 0; th < nThreads; ++th)
+		{
+			own->ops.insert(own->ops.end(), tOps[th].begin(), tOps[th].end());
+			own->lens.insert(own->lens.end(), tLens[th].begin(), tLens[th].end());
+		}
+		if (getenv("FG_KSW_TRACE"))
+			fprintf(stderr, "[ksw] decode on %u threads %.1f ms\n", nThreads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tDec).count());
 	});
 	if (rc != FG_OK) { delete own; return rc; }
 	out->n_pairs = n_pairs;

@@ -1083,18 +1083,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	std::vector<std::vector<float>> statVals;
 	// host threads of the shim: the hardware threads, capped by the cgroup CPU quota (a container that
 	// shows 256 threads but is granted 16 CPUs of time runs the shim slower on 32 threads than on 16)
-	static const unsigned usableCpus = []
-	{
-		unsigned n = std::max(1u, std::thread::hardware_concurrency());
-		if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r"))
-		{
-			char quota[32]; long period = 0;
-			if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
-				n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(quota) / period));
-			fclose(f);
-		}
-		return n;
-	}();
+	const unsigned usableCpus = fg_usable_cpus();
 	unsigned nThreads = std::max(1u, std::min(usableCpus, 32u));
 	if (getenv("FG_SHIM_THREADS")) nThreads = std::max(1, atoi(getenv("FG_SHIM_THREADS")));
 	if (nPrim < 20000) nThreads = 1;

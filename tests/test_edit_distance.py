@@ -227,3 +227,32 @@ def test_device_ksw_cigar_random_against_oracle(built, monkeypatch):
     # the same in several scratch-bounded sub-batches
     monkeypatch.setenv("FG_KSW_SCRATCH_BYTES", str(40 << 20))
     assert ctx.align_cigar_ksw(pairs) == want
+
+
+@pytest.mark.gpu
+def test_device_ksw_lds_rings_equal_literal_state(built, monkeypatch):
+    """Read-sized pairs, bands 64 .. 1024 and beyond: the kernel with the byte state in LDS rings returns what the
+    literal one (whole arrays in memory, pinned above) returns, and both kernels ran."""
+    from flye_amd import gpu
+    rng = np.random.default_rng(44)
+    pairs = []
+    for i in range(120):
+        n = int(rng.integers(3000, 30000))
+        spec = dict(seed=int(rng.integers(1, 1 << 30)), n=n, err=float(rng.choice([0.0, 0.02, 0.12])), hp=int(rng.integers(0, 25)))
+        if i % 3 == 1:
+            spec["shift"] = int(rng.integers(100, 2500))      # lengths apart: the band doubles until it connects the corners
+        if i % 3 == 2:
+            spec["shift"] = int(rng.integers(0, 100))
+        if i % 10 == 9:
+            spec.update(err=1.0, m=int(n * rng.uniform(0.9, 1.1)))
+        pairs.append(edit_pair(spec))
+    pairs += [edit_pair(dict(seed=7, n=40, err=0.1, m=2000)), edit_pair(dict(seed=8, n=2000, err=0.1, m=40))]   # tiny target / query
+    ctx = gpu.Context(17, 0)
+    got = ctx.align_cigar_ksw(pairs)
+    kt = ctx.kernel_times()
+    assert "k_ksw_extz2_lds" in kt and "k_ksw_extz2" in kt
+    monkeypatch.setenv("FG_KSW_LITERAL", "1")
+    lit = ctx.align_cigar_ksw(pairs)
+    assert "k_ksw_extz2_lds" not in ctx.kernel_times()
+    assert got == lit
+    assert len({len(c) for _, c in got}) > 50
