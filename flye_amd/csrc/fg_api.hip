@@ -47,10 +47,17 @@ struct RandStreamGuard {
 template <class F>
 int guarded(fg_ctx* c, F f)
 {
+	int rc = FG_OK;
 	try { f(); return FG_OK; }
-	catch (const FgError& e) { if (c) c->lastError = e.msg; return e.code; }
-	catch (const std::bad_alloc&) { if (c) c->lastError = "host allocation failed"; return FG_ERR_NOMEM; }
-	catch (const std::exception& e) { if (c) c->lastError = e.what(); return FG_ERR_HIP; }
+	catch (const FgError& e) { if (c) c->lastError = e.msg; rc = e.code; }
+	catch (const std::bad_alloc&) { if (c) c->lastError = "host allocation failed"; rc = FG_ERR_NOMEM; }
+	catch (const std::exception& e) { if (c) c->lastError = e.what(); rc = FG_ERR_HIP; }
+	// a call that failed half way may have left launches behind on either stream: nothing of the context's
+	// scratch is reused before they have drained
+	if (c && c->stream2) (void)hipStreamSynchronize(c->stream2);
+	if (c && c->stream3) (void)hipStreamSynchronize(c->stream3);
+	if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+	return rc;
 }
 
 } // namespace
@@ -92,7 +99,12 @@ int fg_create(fg_ctx** out, int device, int kmer_size)
 	if (!c) return FG_ERR_NOMEM;
 	c->device = device;
 	c->k = kmer_size;
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+		hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+		hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
+		hipEventCreateWithFlags(&c->evJoin3, hipEventDisableTiming) != hipSuccess ||
+		hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
+		hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess)
 	{
 		delete c;
 		return FG_ERR_NO_DEVICE;

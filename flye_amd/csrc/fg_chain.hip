@@ -111,8 +111,8 @@ __device__ __forceinline__ void append2_multi(const bool (&a)[LIST_ITEMS], const
 // 244-249 would drop the group anyway, here it never costs k_group_prep a wave)
 __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
 							 const u32* __restrict__ groupFirstCur, const u32* __restrict__ groupLastCur, i32 minOverlap,
-							 u32* __restrict__ list, u32* __restrict__ counts, u32* __restrict__ primCount,
-							 u32* __restrict__ dpSize)
+							 u32* __restrict__ list, u32* __restrict__ listBig, u32 bigMin, u32* __restrict__ counts,
+							 u32* __restrict__ primCount, u32* __restrict__ dpSize)
 {
 	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
 	bool a[LIST_ITEMS], b[LIST_ITEMS];
@@ -133,10 +133,10 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 				ok = (i32)groupLastCur[g] - (i32)groupFirstCur[g] >= minOverlap;
 			start = gend;
 		}
-		a[t] = ok;
-		b[t] = false;
+		a[t] = ok && n <= bigMin;
+		b[t] = ok && n > bigMin;	// groups that k_group_prep handles in global memory
 	}
-	append2_multi(a, b, (u32)g0, list, list, counts);
+	append2_multi(a, b, (u32)g0, list, listBig, counts);
 }
 
 #ifndef FIN_CAP_S
@@ -156,19 +156,23 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 // 7.0 / 6.2 / 6.1 / 6.4 / 8.0 ms against 7.8 ms with the walk in global memory; staging the SORT
 // of 257..1024-hit groups in LDS as well costs more occupancy than it saves latency.)
 // groups that passed the prefilter, by size class
-__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32* __restrict__ listSmall,
+__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32 hugeMin, u32* __restrict__ listSmall,
 						  u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
 {
 	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
-	bool a[LIST_ITEMS], b[LIST_ITEMS];
+	bool a[LIST_ITEMS], b[LIST_ITEMS], h[LIST_ITEMS], none[LIST_ITEMS];
 #pragma unroll
 	for (int t = 0; t < LIST_ITEMS; ++t)
 	{
 		const u32 n = g0 + t < nGroups ? dpSize[g0 + t] : 0u;
 		a[t] = n > 0 && n <= FIN_CAP_S;
-		b[t] = n > FIN_CAP_S;
+		b[t] = n > FIN_CAP_S && n <= hugeMin;
+		h[t] = n > hugeMin;
+		none[t] = false;
 	}
 	append2_multi(a, b, (u32)g0, listSmall, listMid, counts);
+	__syncthreads();	// the helper's shared counters are reused
+	append2_multi(h, none, (u32)g0, listBig, listBig, counts + 2);
 }
 
 // ---- prep --------------------------------------------------------------------------------
@@ -751,56 +755,102 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");
 	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dGroupFirstCur.p,
-						 c->dGroupLastCur.p, (i32)p->min_overlap, c->dListSmall.p,
+						 c->dGroupLastCur.p, (i32)p->min_overlap, c->dListSmall.p, c->dListBig.p, (u32)PREP_CAP,
 						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
-	const u32 nPrep = fetchU32(c, c->dListCnt.p);
-	if (!nPrep) return;
-	{ ScopedK t(c->timer, "k_group_prep");
-#define PREP_ARGS(view) cp, c->dListSmall.p, nPrep, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
+	u32 nPrep[2];
+	HIP_CHECK(hipMemcpyAsync(nPrep, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+	if (!nPrep[0] && !nPrep[1]) return;
+	// Both stages below run their big-group class on the side stream beside the small-group class on the main
+	// one: the classes are disjoint sets of groups, and the big-group kernels end with a handful of waves on an
+	// otherwise idle chip (long serial work per wave).  FG_CHAIN_STREAMS=1 puts everything on the main stream.
+	const bool twoStreams = !(getenv("FG_CHAIN_STREAMS") && atoi(getenv("FG_CHAIN_STREAMS")) == 1);
+	auto fork = [&](bool both) -> hipStream_t
+	{
+		if (!twoStreams || !both) return s;
+		HIP_CHECK(hipEventRecord(c->evFork, s));
+		HIP_CHECK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+		return c->stream2;
+	};
+	auto join = [&](hipStream_t side)
+	{
+		if (side == s) return;
+		HIP_CHECK(hipEventRecord(c->evJoin, side));
+		HIP_CHECK(hipStreamWaitEvent(s, c->evJoin, 0));
+	};
+	{
+		hipStream_t sBig = fork(nPrep[0] && nPrep[1]);
+		const u32* prepList[2] = {c->dListSmall.p, c->dListBig.p};
+#define PREP_ARGS(view, cls) cp, prepList[cls], nPrep[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
 		view, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p
-	  const unsigned gridP = (nPrep + PREP_WAVES - 1) / PREP_WAVES;
-	  if (keyMode == 0)
-		hipLaunchKernelGGL(k_group_prep<u32>, gridP, PREP_WAVES * 64, 0, s,
-						   PREP_ARGS((HitKeyView<u32>{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId})));
-	  else if (keyMode == 1)
-		hipLaunchKernelGGL(k_group_prep<PK>, gridP, PREP_WAVES * 64, 0, s,
-						   PREP_ARGS((HitKeyView<PK>{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId})));
-	  else
-		hipLaunchKernelGGL(k_group_prep<u64>, gridP, PREP_WAVES * 64, 0, s,
-						   PREP_ARGS((HitKeyView<u64>{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId})));
+		for (int cls = 1; cls >= 0; --cls)
+		{
+			if (!nPrep[cls]) continue;
+			hipStream_t on = cls ? sBig : s;
+			ScopedK t(c->timer, "k_group_prep", on);
+			const unsigned gridP = (nPrep[cls] + PREP_WAVES - 1) / PREP_WAVES;
+			if (keyMode == 0)
+				hipLaunchKernelGGL(k_group_prep<u32>, gridP, PREP_WAVES * 64, 0, on,
+								   PREP_ARGS((HitKeyView<u32>{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId}), cls));
+			else if (keyMode == 1)
+				hipLaunchKernelGGL(k_group_prep<PK>, gridP, PREP_WAVES * 64, 0, on,
+								   PREP_ARGS((HitKeyView<PK>{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId}), cls));
+			else
+				hipLaunchKernelGGL(k_group_prep<u64>, gridP, PREP_WAVES * 64, 0, on,
+								   PREP_ARGS((HitKeyView<u64>{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId}), cls));
+		}
 #undef PREP_ARGS
+		join(sBig);
 	}
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
+	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : 1024u;
 	{ ScopedK t(c->timer, "k_dp_list");
-	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, c->dListSmall.p, c->dListDp.p,
+	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, hugeMin, c->dListSmall.p, c->dListDp.p,
 						 c->dListBig.p, c->dListCnt.p); }
-	u32 hc[3];
-	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
+	u32 hc[4];
+	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	const u32* lists[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};	// small, mid, big
-	for (int cls = 1; cls >= 0; --cls)	// the bigger groups first: they set the tail
+	const u32* lists[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};	// <= 256 hits, <= hugeMin, more
+	// three independent chains of two kernels: the <= 256-hit groups on the main stream, the two classes of
+	// larger groups (few groups, long serial work per wave) beside them on side streams
+	const bool side = twoStreams && hc[0] && (hc[1] || hc[2]);
+	hipStream_t sMid = s, sHuge = s;
+	if (side)
 	{
-			if (hc[cls])
-			{
-				ScopedK t(c->timer, "k_chain_dp");
-				hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, cp, lists[cls], hc[cls],
-								   nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, c->dGroupExtSorted.p,
-								   c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p);
-			}
+		HIP_CHECK(hipEventRecord(c->evFork, s));
+		HIP_CHECK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+		HIP_CHECK(hipStreamWaitEvent(c->stream3, c->evFork, 0));
+		sMid = c->stream2; sHuge = c->stream3;
 	}
 #define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
 		qLen, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
-	if (hc[1])
+#define DP_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
+		c->dGroupExtSorted.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p
+	for (int cls = 2; cls >= 1; --cls)	// the longest chains first
 	{
-		ScopedK t(c->timer, "k_chain_finish<global>");
-		hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc[1] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, s,
-						   FIN_ARGS(1));
+		if (!hc[cls]) continue;
+		hipStream_t on = cls == 2 ? sHuge : sMid;
+		{ ScopedK t(c->timer, "k_chain_dp", on);
+		  hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, on, DP_ARGS(cls)); }
+		{ ScopedK t(c->timer, "k_chain_finish<global>", on);
+		  hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc[cls] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, on,
+							 FIN_ARGS(cls)); }
 	}
 	if (hc[0])
 	{
-		ScopedK t(c->timer, "k_chain_finish<lds256>");
-		hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, FIN_WAVES_S>), (hc[0] + FIN_WAVES_S - 1) / FIN_WAVES_S, FIN_WAVES_S * 64,
-						   FIN_CAP_S * 20 * FIN_WAVES_S, s, FIN_ARGS(0));
+		{ ScopedK t(c->timer, "k_chain_dp");
+		  hipLaunchKernelGGL(k_chain_dp, (hc[0] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s, DP_ARGS(0)); }
+		{ ScopedK t(c->timer, "k_chain_finish<lds256>");
+		  hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, FIN_WAVES_S>), (hc[0] + FIN_WAVES_S - 1) / FIN_WAVES_S, FIN_WAVES_S * 64,
+							 FIN_CAP_S * 20 * FIN_WAVES_S, s, FIN_ARGS(0)); }
 	}
+	if (side)
+	{
+		HIP_CHECK(hipEventRecord(c->evJoin, c->stream2));
+		HIP_CHECK(hipStreamWaitEvent(s, c->evJoin, 0));
+		HIP_CHECK(hipEventRecord(c->evJoin3, c->stream3));
+		HIP_CHECK(hipStreamWaitEvent(s, c->evJoin3, 0));
+	}
+#undef DP_ARGS
 #undef FIN_ARGS
 }

@@ -95,6 +95,19 @@ struct PinnedBuf {
 			throw FgError{FG_ERR_NOMEM, "hipHostMalloc of " + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e)};
 		n = count;
 	}
+	// grow and keep the first `used` elements (no copy is pending on them: the caller has synchronised)
+	void reserveKeep(size_t count, size_t used)
+	{
+		if (count <= n) return;
+		count += count / 2;
+		T* q = nullptr;
+		hipError_t e = hipHostMalloc((void**)&q, count * sizeof(T), hipHostMallocDefault);
+		if (e != hipSuccess)
+			throw FgError{FG_ERR_NOMEM, "hipHostMalloc of " + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e)};
+		if (p && used) memcpy(q, p, used * sizeof(T));
+		if (p) (void)hipHostFree(p);
+		p = q; n = count;
+	}
 };
 
 // --- per-kernel timing with HIP events on the library stream -------------------
@@ -111,18 +124,19 @@ struct KernelTimer {
 		if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
 		hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
 	}
-	size_t begin(const char* name)
+	// on: the stream the bracketed launches go to (default: the context's main stream)
+	size_t begin(const char* name, hipStream_t on = nullptr)
 	{
 		if (!enabled) return 0;
 		Ev ev{name, get(), get()};
-		HIP_CHECK(hipEventRecord(ev.a, stream));
+		HIP_CHECK(hipEventRecord(ev.a, on ? on : stream));
 		evs.push_back(ev);
 		return evs.size() - 1;
 	}
-	void end(size_t id)
+	void end(size_t id, hipStream_t on = nullptr)
 	{
 		if (!enabled) return;
-		HIP_CHECK(hipEventRecord(evs[id].b, stream));
+		HIP_CHECK(hipEventRecord(evs[id].b, on ? on : stream));
 	}
 	// forget uncollected measurements (a previous call failed half way): the events go back to the pool
 	void reset()
@@ -157,9 +171,9 @@ struct KernelTimer {
 };
 
 struct ScopedK {
-	KernelTimer& t; size_t id;
-	ScopedK(KernelTimer& t_, const char* name) : t(t_), id(t_.begin(name)) {}
-	~ScopedK() { try { t.end(id); } catch (...) {} }
+	KernelTimer& t; size_t id; hipStream_t on;
+	ScopedK(KernelTimer& t_, const char* name, hipStream_t on_ = nullptr) : t(t_), id(t_.begin(name, on_)), on(on_) {}
+	~ScopedK() { try { t.end(id, on); } catch (...) {} }
 };
 
 // Worker threads of the host shim, kept between calls: spawning 2 x 16 std::threads per fg_overlaps call and
@@ -178,6 +192,9 @@ inline unsigned fg_usable_cpus()
 				n = std::min<unsigned>(n, (unsigned)std::max(1L, atol(quota) / period));
 			fclose(f);
 		}
+		// one process per GPU (torchrun): the ranks of this node share those CPUs
+		if (const char* lw = getenv("LOCAL_WORLD_SIZE"))
+			if (atoi(lw) > 1) n = std::max(1u, n / (unsigned)atoi(lw));
 		return n;
 	}();
 	return cpus;
@@ -238,6 +255,10 @@ struct fg_ctx {
 	int device = 0;
 	int k = 17;
 	hipStream_t stream = nullptr;
+	// side stream of the chaining stage: the big-group kernels run there beside the small-group ones of the main
+	// stream (fork / join by events), so that neither class waits for the other's last waves
+	hipStream_t stream2 = nullptr, stream3 = nullptr;
+	hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin3 = nullptr;
 	std::string lastError;
 	KernelTimer timer;
 
@@ -321,7 +342,15 @@ struct fg_ctx {
 	std::vector<u32> shimNStat;
 	std::vector<u64> shimNMatch;
 
-	~fg_ctx() { if (stream) (void)hipStreamDestroy(stream); }
+	~fg_ctx()
+	{
+		if (evFork) (void)hipEventDestroy(evFork);
+		if (evJoin) (void)hipEventDestroy(evJoin);
+		if (evJoin3) (void)hipEventDestroy(evJoin3);
+		if (stream2) (void)hipStreamDestroy(stream2);
+		if (stream3) (void)hipStreamDestroy(stream3);
+		if (stream) (void)hipStreamDestroy(stream);
+	}
 };
 
 // --- device helpers ----------------------------------------------------------

@@ -390,7 +390,7 @@ __global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildre
 
 template <class KT>
 __global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
-k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount, u32 taskCap,
+k_sort_lds(const SortTask* __restrict__ tasks, u32 nTasks,
 		   KT* __restrict__ hitKey, u32* __restrict__ hitVal, int curBits, u64 narrowMax,
 		   u32* __restrict__ posScratch, u64 nHits)
 {
@@ -402,8 +402,6 @@ k_sort_lds(const SortTask* __restrict__ tasks, const u32* __restrict__ taskCount
 	__shared__ int small[SORT_LDS_WAVES][3 * 8];
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	u32 nTasks = *taskCount;
-	if (nTasks > taskCap) nTasks = taskCap;
 	const u32 ti = blockIdx.x * SORT_LDS_WAVES + wv;
 	if (ti >= nTasks) return;
 	SortTask t = tasks[ti];
@@ -753,12 +751,36 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 		"k_sort_level#18", "k_sort_level#19", "k_sort_level#20", "k_sort_level#21", "k_sort_level#22", "k_sort_level#23",
 		"k_sort_level#24", "k_sort_level#25", "k_sort_level#26", "k_sort_level#27", "k_sort_level#28", "k_sort_level#29",
 		"k_sort_level#30", "k_sort_level#31+"};
+	// FG_SORT_STREAMS=2 (experiment, off): pieces that have become small leave for the LDS kernel at once, on the
+	// side stream beside the next partition level.  Measured at the bench workload: the levels stretch from 12.1 to
+	// 18.8 ms and the pass gets 1 ms LONGER -- small pieces only appear in numbers when the levels are nearly
+	// done, and the two kernels then compete for the same CUs.  Default: one launch at the end.
+	const bool twoStreams = getenv("FG_SORT_STREAMS") && atoi(getenv("FG_SORT_STREAMS")) == 2;
+	const u64 narrowMax = getenv("FG_NARROW_MAX") ? strtoull(getenv("FG_NARROW_MAX"), nullptr, 10) : 0xFFFFFFFFULL;
+	u32 smallDone = 0;
+	bool forked = false;
+	auto launchSmall = [&](u32 upTo, hipStream_t on)
+	{
+		if (upTo > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
+		if (upTo <= smallDone) return;
+		const u32 cntNew = upTo - smallDone;
+		ScopedK t(c->timer, "k_sort_lds", on);
+		hipLaunchKernelGGL(k_sort_lds<KT>, (cntNew + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, on,
+						   smallT + smallDone, cntNew, dK, dV, curBits, narrowMax, c->dTmp32.p, nHits);
+		smallDone = upTo;
+	};
 	int level = 0;
 	while (nBig || nWide)
 	{
+		if (twoStreams && cnt[1] - smallDone >= 4096)
+		{
+			// everything queued so far was written by launches the host has synchronised with
+			if (!forked) { HIP_CHECK(hipEventRecord(c->evFork, s)); HIP_CHECK(hipStreamWaitEvent(c->stream2, c->evFork, 0)); forked = true; }
+			launchSmall(cnt[1], c->stream2);
+		}
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
 		HIP_CHECK(hipMemsetAsync(c->dListCnt.p + 2, 0, 4, s));
-		if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks\n", level, nBig, nWide);
+		if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks, %u small pieces so far\n", level, nBig, nWide, cnt[1]);
 		ScopedK t(c->timer, trace ? levelNames[level < 31 ? level : 31] : "k_sort_level");
 		++level;
 		if (nWide)	// the long poles first
@@ -775,15 +797,11 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 		std::swap(bigA, bigB);
 		std::swap(wideA, wideB);
 	}
-	const u32 nTasks = fetchScalar(c, c->dListCnt.p + 1);
-	if (nTasks > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
-	if (nTasks)
+	launchSmall(cnt[1], s);
+	if (forked)
 	{
-		ScopedK t(c->timer, "k_sort_lds");
-		hipLaunchKernelGGL(k_sort_lds<KT>, (nTasks + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-						   smallT, c->dListCnt.p + 1, smallCap, dK, dV, curBits,
-						   getenv("FG_NARROW_MAX") ? strtoull(getenv("FG_NARROW_MAX"), nullptr, 10) : 0xFFFFFFFFULL,
-						   c->dTmp32.p, nHits);
+		HIP_CHECK(hipEventRecord(c->evJoin, c->stream2));
+		HIP_CHECK(hipStreamWaitEvent(s, c->evJoin, 0));
 	}
 }
 
@@ -808,7 +826,7 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems, nMatchSlots; };
 
 static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, const u32* hq,
-						const u64* hQKmerOff, u32 qa, u32 qb, u64 hitBudget, ChunkResult* res)
+						const u64* hQKmerOff, u32 qa, u32 qb, u64 hitBudget, u64 primBase, ChunkResult* res)
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
@@ -937,10 +955,12 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 		HIP_CHECK(hipMemcpyAsync(c->hMatchOff.p, c->dMatchOff.p, (nPrim + 1) * 8, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipMemcpyAsync(c->hMatchCnt.p, c->dMatchCnt.p, nPrim * 4, hipMemcpyDeviceToHost, s));
 	}
-	c->hPrim.reserve((nPrim + 1) * sizeof(PrimRec));
+	// the primaries of all chunks of the call end up one behind the other in the pinned buffer: this chunk's land
+	// behind the primBase records of the chunks before it
+	c->hPrim.reserveKeep((primBase + nPrim + 1) * sizeof(PrimRec), primBase * sizeof(PrimRec));
 	c->hOff.reserve(3 * (size_t)(nq + 1));
 	{ ScopedK t(c->timer, "copy_results_d2h");
-	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p, c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
+	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p + primBase * sizeof(PrimRec), c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s)); }
@@ -1019,18 +1039,15 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	const bool keepAln = p->keep_alignment;
 	std::vector<u64> mData, mOff(1, 0);	// keep_alignment: compacted kmerMatches per primary
-	std::vector<PrimRec> primStore;		// only used when there is more than one chunk
 	std::vector<u64> primOffAll(nq + 1, 0);
-	const bool single = todo.size() == 1;
 	u64 nPrim = 0;
 	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0;
-	bool usedStore = false;
 	while (!todo.empty())
 	{
 		const auto [qa, qb] = todo.back();
 		todo.pop_back();
 		ChunkResult cr;
-		if (!deviceChunk(c, p, forceLocal, hq.data(), hQKmerOff.data(), qa, qb, hitBudget, &cr))
+		if (!deviceChunk(c, p, forceLocal, hq.data(), hQKmerOff.data(), qa, qb, hitBudget, nPrim, &cr))
 		{
 			const u32 mid = qa + (qb - qa) / 2;
 			todo.push_back({mid, qb});
@@ -1040,12 +1057,6 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		out->seed_hits += cr.nHits; out->dp_groups += cr.dpGroups; out->dp_elements += cr.dpElems;
 		const u64* off = c->hOff.p;
 		for (u32 i = 0; i < qb - qa; ++i) primOffAll[qa + i + 1] = nPrim + off[i + 1];
-		if (!(single && todo.empty() && !usedStore))
-		{
-			usedStore = true;
-			const PrimRec* src = (const PrimRec*)c->hPrim.p;
-			primStore.insert(primStore.end(), src, src + cr.nPrim);
-		}
 		if (keepAln)
 		{
 			mData.reserve(mData.size() + cr.nMatchSlots);
@@ -1061,7 +1072,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	HIP_CHECK(hipEventRecord(evB, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	const PrimRec* hPrim = usedStore ? primStore.data() : (const PrimRec*)c->hPrim.p;
+	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
 	const u64* hPrimOff = primOffAll.data();
 	const auto tHost1 = std::chrono::steady_clock::now();
 

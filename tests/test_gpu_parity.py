@@ -402,6 +402,18 @@ def test_internal_chunking_is_invisible(built, monkeypatch):
     monkeypatch.delenv("FG_NARROW_MAX")
     monkeypatch.delenv("FG_PACKED_KEYS")
     monkeypatch.delenv("FG_FORCE_KEY64")
+    # the stream layout is invisible too: chaining classes all on the main stream, LDS sort batches on the side
+    # stream, group classes cut elsewhere
+    for env in ({"FG_CHAIN_STREAMS": "1"}, {"FG_SORT_STREAMS": "2"}, {"FG_CHAIN_HUGE_MIN": "300"},
+                {"FG_CHAIN_STREAMS": "1", "FG_KMER_BUDGET": "200000"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        alt = det.getSeqOverlapsBatch(q, maxOverlaps=11)
+        got = (alt.recs.tobytes(), alt.query_off.tobytes(), alt.stats.tobytes(), alt.seed_hits,
+               alt.dp_groups, alt.dp_elements, alt.match_off.tobytes(), alt.matches.tobytes())
+        assert got == base, env
+        for k_ in env:
+            monkeypatch.delenv(k_)
 
 
 def test_edge_cases(built):
