@@ -803,7 +803,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		join(sBig);
 	}
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
-	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : 1024u;
+	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : 4096u;
 	{ ScopedK t(c->timer, "k_dp_list");
 	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, hugeMin, c->dListSmall.p, c->dListDp.p,
 						 c->dListBig.p, c->dListCnt.p); }
