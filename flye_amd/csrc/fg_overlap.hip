@@ -1198,9 +1198,17 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				o.score = r.score; o.seq_divergence = div[j];
 				o.chain_length = r.chainLength; o.filtered_positions = r.filtered;
 				o.edit_distance = r.editDistance; o.hpc_len_cur = r.hpcLenCur; o.hpc_len_ext = r.hpcLenExt;
-				*dst++ = o;
+				// the records are written once and not read again by this thread: streaming stores keep the
+				// read-for-ownership of every destination line off the memory bus
+				static_assert(sizeof(fg_overlap_rec) % 4 == 0, "record of 32-bit fields");
+				const int* src32 = (const int*)&o;
+				int* dst32 = (int*)dst;
+#pragma unroll
+				for (unsigned w4 = 0; w4 < sizeof(fg_overlap_rec) / 4; ++w4) __builtin_nontemporal_store(src32[w4], dst32 + w4);
+				++dst;
 			}
 		}
+		__builtin_ia32_sfence();
 	};
 	runThreads(pass2);
 	out->n_recs = own->nRecs;
