@@ -103,12 +103,15 @@ int fg_create(fg_ctx** out, int device, int kmer_size)
 		hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
 		hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess ||
 		hipEventCreateWithFlags(&c->evJoin3, hipEventDisableTiming) != hipSuccess ||
+		hipEventCreateWithFlags(&c->evOff, hipEventDisableTiming) != hipSuccess ||
 		hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming) != hipSuccess ||
 		hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming) != hipSuccess)
 	{
 		delete c;
 		return FG_ERR_NO_DEVICE;
 	}
+	for (auto& e : c->evPiece)
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return FG_ERR_NO_DEVICE; }
 	c->timer.stream = c->stream;
 	*out = c;
 	return FG_OK;

@@ -259,6 +259,11 @@ struct fg_ctx {
 	// stream (fork / join by events), so that neither class waits for the other's last waves
 	hipStream_t stream2 = nullptr, stream3 = nullptr;
 	hipEvent_t evFork = nullptr, evJoin = nullptr, evJoin3 = nullptr;
+	// the primaries of a chunk leave for the host in FG_D2H_PIECES copies; the shim's threads start on a piece as
+	// soon as ITS copy has landed (piece i covers the primaries below pieceEnd[i], counted over the whole call)
+#define FG_D2H_PIECES 4
+	hipEvent_t evOff = nullptr, evPiece[FG_D2H_PIECES] = {};
+	unsigned long long pieceEnd[FG_D2H_PIECES] = {};
 	std::string lastError;
 	KernelTimer timer;
 
@@ -347,6 +352,8 @@ struct fg_ctx {
 		if (evFork) (void)hipEventDestroy(evFork);
 		if (evJoin) (void)hipEventDestroy(evJoin);
 		if (evJoin3) (void)hipEventDestroy(evJoin3);
+		if (evOff) (void)hipEventDestroy(evOff);
+		for (auto e : evPiece) if (e) (void)hipEventDestroy(e);
 		if (stream2) (void)hipStreamDestroy(stream2);
 		if (stream3) (void)hipStreamDestroy(stream3);
 		if (stream) (void)hipStreamDestroy(stream);

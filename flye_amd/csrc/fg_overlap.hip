@@ -22,6 +22,7 @@
 // (ascending curPos, per k-mer ascending stored position).
 #include "fg_ctx.h"
 #include "fg_wavesort.h"
+#include <atomic>
 
 #include <algorithm>
 #include <cmath>
@@ -957,14 +958,30 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	}
 	// the primaries of all chunks of the call end up one behind the other in the pinned buffer: this chunk's land
 	// behind the primBase records of the chunks before it
-	c->hPrim.reserveKeep((primBase + nPrim + 1) * sizeof(PrimRec), primBase * sizeof(PrimRec));
+	if ((primBase + nPrim + 1) * sizeof(PrimRec) > c->hPrim.n)
+	{
+		HIP_CHECK(hipStreamSynchronize(s));		// copies of earlier chunks may still be on their way into the old buffer
+		c->hPrim.reserveKeep((primBase + nPrim + 1) * sizeof(PrimRec), primBase * sizeof(PrimRec));
+	}
 	c->hOff.reserve(3 * (size_t)(nq + 1));
 	{ ScopedK t(c->timer, "copy_results_d2h");
-	  if (nPrim) HIP_CHECK(hipMemcpyAsync(c->hPrim.p + primBase * sizeof(PrimRec), c->dPrimOut.p, nPrim * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
-	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s)); }
-	HIP_CHECK(hipStreamSynchronize(s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipEventRecord(c->evOff, s));
+	  // the records in pieces, an event behind each: the caller does not wait for them here (the host shim's
+	  // threads wait for the piece they read)
+	  for (int i = 0; i < FG_D2H_PIECES; ++i)
+	  {
+		  const u64 a = nPrim * i / FG_D2H_PIECES, b = nPrim * (i + 1) / FG_D2H_PIECES;
+		  if (b > a)
+			  HIP_CHECK(hipMemcpyAsync(c->hPrim.p + (primBase + a) * sizeof(PrimRec), c->dPrimOut.p + a * sizeof(PrimRec),
+									   (b - a) * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
+		  HIP_CHECK(hipEventRecord(c->evPiece[i], s));
+		  c->pieceEnd[i] = primBase + b;
+	  } }
+	HIP_CHECK(hipEventSynchronize(c->evOff));
+	if (keepAln) HIP_CHECK(hipStreamSynchronize(s));		// the match lists are read by the caller right away
 	res->nPrim = nPrim;
 	res->dpGroups = 0; res->dpElems = 0;
 	for (u32 i = 0; i < nq; ++i) { res->dpGroups += c->hOff.p[(nq + 1) + i]; res->dpElems += c->hOff.p[2 * (size_t)(nq + 1) + i]; }
@@ -1071,10 +1088,25 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		nPrim += cr.nPrim;
 	}
 	HIP_CHECK(hipEventRecord(evB, s));
-	HIP_CHECK(hipStreamSynchronize(s));
+	// no wait for the last chunk's records here: piece by piece in the shim's first pass
 	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
 	const u64* hPrimOff = primOffAll.data();
 	const auto tHost1 = std::chrono::steady_clock::now();
+	const int dev = c->device;
+	std::atomic<int> waitErr{0};		// worker threads must not throw
+	auto waitPrim = [c, dev, &waitErr](u64 endIdx)
+	{
+		// primaries below endIdx are on the host when the first piece reaching that far has landed (copies of one
+		// stream complete in order; earlier chunks' pieces lie below this chunk's first)
+		(void)hipSetDevice(dev);
+		for (int i = 0; i < FG_D2H_PIECES; ++i)
+			if (c->pieceEnd[i] >= endIdx || i == FG_D2H_PIECES - 1)
+			{
+				const hipError_t e = hipEventSynchronize(c->evPiece[i]);
+				if (e != hipSuccess) waitErr.store((int)e);
+				return;
+			}
+	};
 
 	// ---- host shim: floats with the host libm, the gate, prefix rule, window stats ----
 	// two passes over the queries, both fanned out over host threads: (1) divergence,
@@ -1105,6 +1137,8 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		struct Wnd { i32 range; float div; };
 		std::vector<Wnd> wnd;
 		const u32 q0 = (u32)((u64)nq * t / nThreads), q1 = (u32)((u64)nq * (t + 1) / nThreads);
+		if (q1 > q0) waitPrim(hPrimOff[q1]);
+		if (waitErr.load()) return;
 		for (u32 qi = q0; qi < q1; ++qi)
 		{
 			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
@@ -1150,6 +1184,8 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	};
 	auto runThreads = [&](const std::function<void(unsigned)>& fn) { c->shimPool.run(nThreads, fn); };
 	runThreads(pass1);
+	HIP_CHECK(hipStreamSynchronize(s));		// everything has landed by now; also surfaces a failed copy
+	if (waitErr.load()) throw FgError{FG_ERR_HIP, std::string("waiting for the result copy: ") + hipGetErrorString((hipError_t)waitErr.load())};
 	own->queryOff[0] = 0;
 	for (u32 qi = 0; qi < nq; ++qi)
 	{
