@@ -8,6 +8,7 @@
 // the device does not hold (their sequence travels with the request).
 #include "../../include/flye_gpu_bridge.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -62,6 +63,23 @@ struct QuickReq {
 	std::unique_ptr<ReadResult> res;
 };
 
+// Read-ahead of the quick path, per (maxOverlaps, forceLocal) class.  The reference's callers walk their
+// container in id order from N worker threads (processInParallel hands out consecutive indices:
+// OverlapContainer::findAllOverlaps overlap.cpp:586-601, estimateOverlaperParameters :786-806, ReadAligner::
+// alignReads read_aligner.cpp:195-217), so with one getSeqOverlaps call per thread in flight a device call would
+// carry N reads.  Every device call therefore also computes the `ahead` records that follow the highest id asked
+// for (same strand); their results wait here until their own call arrives.  `ahead` doubles while the results
+// are being picked up and halves when they are not (a caller that jumps around): the cost of a wrong guess is
+// device work nobody reads, never a wrong answer.
+struct SpecClass {
+	std::unordered_map<uint32_t, std::unique_ptr<ReadResult>> ready;	// by record id
+	std::deque<uint32_t> order;			// insertion order, for eviction
+	uint32_t frontier[2] = {0, 0};		// highest id computed so far, per strand (0 = none)
+	uint32_t ahead = 32;
+	uint64_t hitsSince = 0;				// results picked up since the last speculative call
+	bool wanted = false;				// low-water mark reached: compute more without waiting for a miss
+};
+
 } // namespace
 
 struct fgb_container {
@@ -76,8 +94,10 @@ struct fgb_container {
 	std::deque<uint32_t> lazyQ;		// forward ids somebody waits for
 	std::deque<uint32_t> prefetchQ;	// forward ids nobody waits for yet
 	std::deque<QuickReq*> quickQ;
+	std::map<std::pair<int32_t, uint8_t>, SpecClass> spec;
+	uint32_t maxAhead = 4096;			// FGB_READ_AHEAD (0 switches the read-ahead off)
 	std::vector<float> divStats;
-	fgb_stats stats{0, 0, 0, 0, 0};
+	fgb_stats stats{0, 0, 0, 0, 0, 0, 0};
 	bool stop = false;
 	std::thread worker;
 
@@ -91,6 +111,12 @@ struct fgb_container {
 		return id >= base && id - base < 2 * cnt;
 	}
 	bool inIndexed(uint32_t id) const { return id >= firstId && id - firstId < 2 * nFwd; }
+	bool specWanted() const
+	{
+		for (auto& kv : spec) if (kv.second.wanted) return true;
+		return false;
+	}
+	void dropSpeculated() { spec.clear(); }		// results computed under parameters that no longer hold
 };
 
 int fgb_container::deviceCall(const fg_detector_params& p, const std::vector<uint32_t>& ids, int32_t mo, uint8_t fl,
@@ -124,7 +150,7 @@ void fgb_container::run()
 	std::unique_lock<std::mutex> lk(mu);
 	while (true)
 	{
-		cvWork.wait(lk, [&] { return stop || !lazyQ.empty() || !quickQ.empty() || !prefetchQ.empty(); });
+		cvWork.wait(lk, [&] { return stop || !lazyQ.empty() || !quickQ.empty() || !prefetchQ.empty() || specWanted(); });
 		if (stop) break;
 		// let the other worker threads of the caller pile their requests on
 		if (lazyQ.size() + quickQ.size() < maxBatch && lingerUs)
@@ -177,7 +203,7 @@ void fgb_container::run()
 		}
 
 		// ---- quick requests: one device call per (maxOverlaps, forceLocal, native / foreign) class ----
-		if (!quickQ.empty())
+		if (!quickQ.empty() || specWanted())
 		{
 			std::map<std::tuple<int32_t, uint8_t, bool>, std::vector<QuickReq*>> classes;
 			size_t taken = 0;
@@ -186,10 +212,45 @@ void fgb_container::run()
 				QuickReq* r = quickQ.front(); quickQ.pop_front(); ++taken;
 				classes[std::make_tuple(r->maxOverlaps, r->forceLocal, r->words != nullptr)].push_back(r);
 			}
+			for (auto& kv : spec)
+				if (kv.second.wanted) classes[std::make_tuple(kv.first.first, kv.first.second, false)];	// may be a call of its own
+			// the records to compute ahead, class by class (native ids only)
+			std::map<std::tuple<int32_t, uint8_t, bool>, std::vector<uint32_t>> aheadIds;
+			if (maxAhead)
+				for (auto& kv : classes)
+				{
+					if (std::get<2>(kv.first)) continue;
+					SpecClass& sc = spec[std::make_pair(std::get<0>(kv.first), std::get<1>(kv.first))];
+					// adapt: the last speculative call's results were (not) picked up
+					if (sc.hitsSince * 2 >= sc.ahead) sc.ahead = std::min(sc.ahead * 2, maxAhead);
+					else if (!kv.second.empty() && sc.hitsSince * 8 < sc.ahead) sc.ahead = std::max(sc.ahead / 2, 8u);
+					sc.hitsSince = 0;
+					sc.wanted = false;
+					const uint32_t base = qNFwd ? qFirstId : firstId, cnt = qNFwd ? qNFwd : nFwd;
+					std::vector<uint32_t>& ids = aheadIds[kv.first];
+					for (int strand = 0; strand < 2; ++strand)
+					{
+						uint32_t top = 0; bool any = false;
+						for (QuickReq* r : kv.second)
+							if ((int)(r->id & 1u) == strand) { top = any ? std::max(top, r->id) : r->id; any = true; }
+						if (!any && !(kv.second.empty() && sc.frontier[strand])) continue;	// nobody walks this strand
+						// from the frontier, unless the callers have moved past it or far back behind it (a new walk)
+						uint32_t id = sc.frontier[strand];
+						if (any && (top > id || id - top > 16u * maxAhead)) id = top;
+						uint32_t added = 0;
+						while (added < sc.ahead && (uint64_t)id + 2 < (uint64_t)base + 2ULL * cnt)
+						{
+							id += 2;
+							if (sc.ready.find(id) == sc.ready.end()) { ids.push_back(id); ++added; }
+						}
+						if (added) sc.frontier[strand] = id;
+					}
+				}
 			const fg_detector_params p = params;
 			lk.unlock();
 			std::vector<float> allSt;
-			size_t calls = 0, reads = 0;
+			size_t calls = 0, reads = 0, specReads = 0;
+			std::map<std::tuple<int32_t, uint8_t, bool>, std::vector<std::unique_ptr<ReadResult>>> aheadRes;
 			for (auto& kv : classes)
 			{
 				const bool foreign = std::get<2>(kv.first);
@@ -217,10 +278,13 @@ void fgb_container::run()
 				}
 				else
 					for (QuickReq* r : reqs) qids.push_back(r->id);
+				const std::vector<uint32_t>& extra = aheadIds[kv.first];
+				qids.insert(qids.end(), extra.begin(), extra.end());
+				if (qids.empty()) continue;
 				std::vector<std::unique_ptr<ReadResult>> res;
 				if (rc == FG_OK) rc = deviceCall(p, qids, std::get<0>(kv.first), std::get<1>(kv.first), res);
 				if (foreign) (void)fg_set_queries(ctx, 0, nullptr, nullptr, nullptr, 0);
-				++calls; reads += qids.size();
+				++calls; reads += qids.size(); specReads += extra.size();
 				for (size_t i = 0; i < reqs.size(); ++i)
 				{
 					reqs[i]->status = rc;
@@ -229,10 +293,32 @@ void fgb_container::run()
 					allSt.insert(allSt.end(), res[i]->stats.begin(), res[i]->stats.end());
 					reqs[i]->res = std::move(res[i]);
 				}
+				if (rc == FG_OK)
+				{
+					std::vector<std::unique_ptr<ReadResult>>& keep = aheadRes[kv.first];
+					for (size_t i = 0; i < extra.size(); ++i) keep.push_back(std::move(res[reqs.size() + i]));
+				}
 			}
 			lk.lock();
-			stats.device_calls += calls; stats.reads_computed += reads;
+			stats.device_calls += calls; stats.reads_computed += reads; stats.reads_ahead += specReads;
 			for (auto& kv : classes) for (QuickReq* r : kv.second) r->done = true;
+			if (p.max_divergence == params.max_divergence)		// the threshold may have moved while the device worked
+				for (auto& kv : aheadRes)
+				{
+					SpecClass& sc = spec[std::make_pair(std::get<0>(kv.first), std::get<1>(kv.first))];
+					const std::vector<uint32_t>& ids = aheadIds[kv.first];
+					for (size_t i = 0; i < kv.second.size(); ++i)
+					{
+						sc.ready[ids[i]] = std::move(kv.second[i]);
+						sc.order.push_back(ids[i]);
+					}
+					while (sc.ready.size() > 2 * (size_t)maxAhead && !sc.order.empty())
+					{
+						sc.ready.erase(sc.order.front());		// oldest first; ids already picked up are no-ops
+						sc.order.pop_front();
+					}
+					while (sc.order.size() > 4 * (size_t)maxAhead) sc.order.pop_front();
+				}
 			divStats.insert(divStats.end(), allSt.begin(), allSt.end());
 			cvDone.notify_all();
 		}
@@ -249,6 +335,26 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 	std::unique_lock<std::mutex> lk(c->mu);
 	++c->stats.requests;
 	if (c->stop) return FG_ERR_STATE;
+	if (!r.words && c->maxAhead)
+	{
+		auto sit = c->spec.find(std::make_pair(r.maxOverlaps, r.forceLocal));
+		if (sit != c->spec.end())
+		{
+			SpecClass& sc = sit->second;
+			auto it = sc.ready.find(r.id);
+			if (it != sc.ready.end())
+			{
+				r.res = std::move(it->second);
+				sc.ready.erase(it);
+				++sc.hitsSince; ++c->stats.ahead_hits;
+				c->divStats.insert(c->divStats.end(), r.res->stats.begin(), r.res->stats.end());
+				// keep the device ahead of the callers: top up when half of the last call's results are gone
+				if (!sc.wanted && sc.ready.size() * 2 < sc.ahead) { sc.wanted = true; c->cvWork.notify_one(); }
+				r.done = true; r.status = FG_OK;
+				return FG_OK;
+			}
+		}
+	}
 	c->quickQ.push_back(&r);
 	c->cvWork.notify_one();
 	c->cvDone.wait(lk, [&] { return r.done; });
@@ -267,6 +373,7 @@ int fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params
 		c->ctx = ctx; c->params = *params;
 		c->maxBatch = max_batch ? max_batch : 4096;
 		c->lingerUs = linger_us;
+		if (getenv("FGB_READ_AHEAD")) c->maxAhead = (uint32_t)std::max(0, atoi(getenv("FGB_READ_AHEAD")));
 		const int rc = fg_container_info(ctx, &c->firstId, &c->nFwd, &c->qFirstId, &c->qNFwd);
 		if (rc != FG_OK) return rc;
 		fgb_container* raw = c.release();
@@ -383,6 +490,7 @@ int fgb_set_divergence_threshold(fgb_container* c, float max_divergence)
 {
 	if (!c) return FG_ERR_ARG;
 	std::lock_guard<std::mutex> g(c->mu);
+	if (c->params.max_divergence != max_divergence) c->dropSpeculated();
 	c->params.max_divergence = max_divergence;
 	return FG_OK;
 }

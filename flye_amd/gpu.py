@@ -83,7 +83,8 @@ class CigarBatch(C.Structure):
 
 class BridgeStats(C.Structure):
     _fields_ = [("device_calls", C.c_uint64), ("reads_computed", C.c_uint64), ("requests", C.c_uint64),
-                ("cache_hits", C.c_uint64), ("cached_overlaps", C.c_uint64)]
+                ("cache_hits", C.c_uint64), ("cached_overlaps", C.c_uint64), ("reads_ahead", C.c_uint64),
+                ("ahead_hits", C.c_uint64)]
 
 
 class KernelTime(C.Structure):

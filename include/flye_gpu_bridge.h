@@ -96,6 +96,8 @@ struct fgb_stats {
 	uint64_t requests;         /* fgb_lazy + fgb_quick calls */
 	uint64_t cache_hits;       /* fgb_lazy calls answered without waiting for the device */
 	uint64_t cached_overlaps;  /* OverlapContainer::indexSize() */
+	uint64_t reads_ahead;      /* of reads_computed: records computed ahead of their request (quick path) */
+	uint64_t ahead_hits;       /* fgb_quick / fgb_quick_ex calls answered from those */
 };
 void fgb_get_stats(fgb_container* c, struct fgb_stats* out);
 
