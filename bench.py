@@ -137,7 +137,7 @@ def main():
     # timed passes they run side by side on three streams, where an event-bracketed duration includes the time a
     # kernel shares the chip with the others.  The serial pass says which kernel holds the device longest by itself.
     serial_ktimes = {}
-    if rank == 0:
+    if rank == 0 and not os.environ.get("FLYE_BENCH_NO_SERIAL_PASS"):     # (the counter passes of tools/profile_round.sh want ONE pass)
         os.environ["FG_CHAIN_STREAMS"] = "1"
         step()
         serial_ktimes = {k_: v_ for k_, v_ in ctx.kernel_times().items() if not k_.startswith("host:")}
@@ -174,6 +174,8 @@ def main():
         # within 5 % of the maximum the kernel with the fewest launches is taken, so that the line does not
         # flip between two kernels from run to run)
         # dominance by the serial pass's exclusive times; duration and launch count from the timed region
+        if not serial_ktimes:
+            serial_ktimes = {k_: v_ for k_, v_ in ktimes.items() if not k_.startswith("host:")}
         top = max(v_[0] for v_ in serial_ktimes.values())
         dom_name = min((kv for kv in serial_ktimes.items() if kv[1][0] >= 0.95 * top), key=lambda kv: (kv[1][1], -kv[1][0]))[0]
         dom_sec, dom_n = ktimes[dom_name]
@@ -214,6 +216,9 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+                         "launch": ("one level of the hit sort = the k_sort_level launch together with the k_sort_wide launch "
+                                    "for pieces above 16 k hits (levels 0-7 only) and the k_sort_route launch behind it, "
+                                    "bracketed by one pair of HIP events") if dom_name == "k_sort_level" else "one kernel launch",
                          "dominant_by": "exclusive device time in an untimed pass with the chaining classes serialised "
                                         "(FG_CHAIN_STREAMS=1); ms per pass there: " +
                                         ", ".join(f"{k_} {v_[0] * 1e3:.1f}" for k_, v_ in
@@ -334,7 +339,27 @@ def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=250e6)
                          min_overlap=min_ovlp, query_limit=n, ovlp_out=ov)
         wall = time.perf_counter() - t0
         same = records_equal_ref_file(gres.recs[:int(gres.query_off[n])], ov)
+        # the same program linked with our seam definitions in front (integration/flye_seam.cpp: index build and
+        # getSeqOverlaps on the device, batched over its worker threads): what the kernels buy the reference's own
+        # stage, host side included.  Same FASTA, flags and threads; the overlap file must be byte-identical.
+        seam = None
+        if O.have_ref_gpu():
+            import filecmp
+            ov2 = os.path.join(tmp, "ovlp_seam.txt")
+            try:
+                t1 = time.perf_counter()
+                i2 = O.run_ref(fa, params_string=config.params_string(preset), threads=threads, min_read_len=0,
+                               min_overlap=min_ovlp, query_limit=n, ovlp_out=ov2, binary=O.REF_DUMPER_GPU)
+                seam = {"overlap_s": i2["overlap_s"], "index_s": i2["index_s"], "process_s": round(time.perf_counter() - t1, 2),
+                        "value": round(i2["queried_bp"] / i2["overlap_s"] / 1e9, 6), "unit": "Gbp/s",
+                        "output_byte_identical_to_reference": filecmp.cmp(ov, ov2, shallow=False),
+                        "what": "the reference's own program (oracle/_ref/ref_dumper_gpu = the same driver and Flye sources "
+                                "with VertexIndex builds and OverlapDetector::getSeqOverlaps replaced at link time), "
+                                f"{threads} worker threads, one getSeqOverlaps call each in flight"}
+            except Exception as e:  # noqa: BLE001
+                seam = {"error": str(e)[:200]}
     return {"value": round(info["queried_bp"] / info["overlap_s"] / 1e9, 6), "unit": "Gbp/s", "cores": threads,
+            "reference_program_with_device_seams": seam,
             "kind": "reference", "overlap_s": info["overlap_s"], "index_s": info["index_s"], "load_s": info["load_s"],
             "overlaps": info["overlaps"],
             "sample": f"first {n} forward reads ({info['queried_bp']} bp) of the same workload through the reference's "

@@ -354,6 +354,66 @@ def test_batching_container_under_threads(built):
     assert tight.tobytes() == det.getSeqOverlapsBatch(np.array([0], np.uint32)).recs.tobytes()
 
 
+def test_bridge_read_ahead(built):
+    """The quick path computes the records behind the highest id asked for in the same device call: worker threads that
+    walk the container in id order, one getSeqOverlaps call each in flight (processInParallel's pattern), are
+    answered from those results in a few device calls; lists stay the direct ones, for a walk in id order, for
+    random jumps, and across a change of the divergence threshold (results computed ahead under the old one are
+    dropped)."""
+    import itertools
+    import threading
+    from flye_amd import config, gpu, synth
+    rs = synth.simulate(seed=37, genome_len=80_000, coverage=30, kind="pb_raw", n_tandems=20).filter_min_len(1000)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = 0.3
+    allq = np.arange(0, 2 * rs.n, dtype=np.uint32)
+    direct = det.getSeqOverlapsBatch(allq)
+    oc = gpu.BatchingOverlapContainer(det, max_batch=64, linger_us=100)
+    errors = []
+
+    def walk(ids, want):
+        counter = itertools.count()
+        lock = threading.Lock()
+
+        def worker():
+            try:
+                while True:
+                    with lock:
+                        j = next(counter)
+                    if j >= len(ids):
+                        return
+                    rid = int(ids[j])
+                    assert oc.quickSeqOverlaps(rid, 0, False).tobytes() == want.of(rid).tobytes(), rid
+            except Exception as e:      # noqa: BLE001
+                errors.append(repr(e))
+        th = [threading.Thread(target=worker) for _ in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    fwd = allq[::2]
+    walk(fwd, direct)
+    assert not errors, errors[:3]
+    s1 = oc.stats()
+    assert s1["ahead_hits"] > 0.7 * len(fwd), s1          # most calls never waited for the device
+    assert s1["device_calls"] < len(fwd) // 16, s1        # 8 callers in flight, yet far fewer calls than reads / 8
+    # the reverse strand, then random jumps over both strands
+    walk(allq[1::2], direct)
+    walk(np.random.default_rng(1).permutation(allq), direct)
+    assert not errors, errors[:3]
+    # a new threshold: nothing computed ahead under the old one may be handed out
+    walk(fwd[: len(fwd) // 2], direct)
+    oc.setDivergenceThreshold(0.05)
+    det.p.max_divergence = 0.05
+    tight = det.getSeqOverlapsBatch(allq)
+    walk(fwd[len(fwd) // 2:], tight)
+    assert not errors, errors[:3]
+    assert sum(len(tight.of(int(i))) for i in fwd) < sum(len(direct.of(int(i))) for i in fwd)   # the gate did change lists
+    oc.close()
+
+
 def test_internal_chunking_is_invisible(built, monkeypatch):
     """fg_overlaps cuts big batches into chunks bounded by k-mers / seed hits (and halves a
     chunk whose hits exceed the budget); results must not depend on the cut."""

@@ -14,6 +14,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done" > $OUT/progress
+export FLYE_BENCH_NO_SERIAL_PASS=1   # the counter passes: index build + exactly ONE overlap pass
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2> $OUT/fetch.err
 echo "fetch done" >> $OUT/progress
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu > /dev/null 2> $OUT/write.err
