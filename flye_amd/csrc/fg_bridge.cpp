@@ -71,12 +71,22 @@ struct QuickReq {
 // for (same strand); their results wait here until their own call arrives.  `ahead` doubles while the results
 // are being picked up and halves when they are not (a caller that jumps around): the cost of a wrong guess is
 // device work nobody reads, never a wrong answer.
+//
+// The assemble stage asks differently: Extender::extendDisjointig takes the overlaps of the current read and then
+// asks for the reads on the other side of them, longest overlap first, until one qualifies (extender.cpp:44-98),
+// and moves on to that read.  For the lazy class (maxOverlaps 0, not local) the forward records named by the
+// overlaps of a read that was asked for are therefore computed ahead as well ("neighbours"), under a budget of
+// their own that adapts the same way.
+struct SpecEntry { std::unique_ptr<ReadResult> res; uint8_t origin; };		// origin 0: next in id order, 1: neighbour
 struct SpecClass {
-	std::unordered_map<uint32_t, std::unique_ptr<ReadResult>> ready;	// by record id
+	std::unordered_map<uint32_t, SpecEntry> ready;	// by record id
 	std::deque<uint32_t> order;			// insertion order, for eviction
 	uint32_t frontier[2] = {0, 0};		// highest id computed so far, per strand (0 = none)
-	uint32_t ahead = 32;
-	uint64_t hitsSince = 0;				// results picked up since the last speculative call
+	uint32_t ahead = 32, aheadNb = 256;
+	uint64_t hitsSince = 0, hitsNbSince = 0;	// results picked up since the last speculative call, by origin
+	uint64_t computedNbSince = 0, computedSince = 0;
+	std::deque<uint32_t> neighbours;	// forward ids named by results handed out, not computed yet
+	std::unordered_map<uint32_t, uint8_t> seen;	// ids ever computed or queued in this class (bounds repeated work)
 	bool wanted = false;				// low-water mark reached: compute more without waiting for a miss
 };
 
@@ -117,6 +127,29 @@ struct fgb_container {
 		return false;
 	}
 	void dropSpeculated() { spec.clear(); }		// results computed under parameters that no longer hold
+	// the reads Extender looks at next, given the overlaps of the read just handed out: all the reads they name
+	// (it sorts by curRange, extender.cpp:53-55, and stops at the first that qualifies; the read it moves on to
+	// shares most of its neighbours with this one), longest overlap first.  Every record is queued once per class
+	// (`seen`), so the work this adds is bounded by one more pass over the container however the caller walks.
+	void queueNeighbours(SpecClass& sc, const RecList& recs)
+	{
+		std::vector<std::pair<int32_t, uint32_t>> cand;
+		cand.reserve(recs.size());
+		for (const auto& o : recs)
+		{
+			const uint32_t e = o.ext_id & ~1u;
+			if (!validQueryId(e) || sc.seen.count(e)) continue;
+			sc.seen[e] = 1;
+			cand.push_back(std::make_pair(-(o.cur_end - o.cur_begin), e));
+		}
+		std::sort(cand.begin(), cand.end());
+		// the dozen longest overlaps of the newest read first (several callers walk different places at once and
+		// a call's budget is finite), the rest behind everything queued so far
+		const size_t top = std::min<size_t>(cand.size(), 12);
+		for (size_t i = top; i-- > 0;) sc.neighbours.push_front(cand[i].second);
+		for (size_t i = top; i < cand.size(); ++i) sc.neighbours.push_back(cand[i].second);
+		while (sc.neighbours.size() > 16 * (size_t)maxAhead) sc.neighbours.pop_back();
+	}
 };
 
 int fgb_container::deviceCall(const fg_detector_params& p, const std::vector<uint32_t>& ids, int32_t mo, uint8_t fl,
@@ -216,15 +249,20 @@ void fgb_container::run()
 				if (kv.second.wanted) classes[std::make_tuple(kv.first.first, kv.first.second, false)];	// may be a call of its own
 			// the records to compute ahead, class by class (native ids only)
 			std::map<std::tuple<int32_t, uint8_t, bool>, std::vector<uint32_t>> aheadIds;
+			std::map<std::tuple<int32_t, uint8_t, bool>, size_t> nbStart;	// aheadIds[..][nbStart ..) are neighbours
 			if (maxAhead)
 				for (auto& kv : classes)
 				{
 					if (std::get<2>(kv.first)) continue;
 					SpecClass& sc = spec[std::make_pair(std::get<0>(kv.first), std::get<1>(kv.first))];
-					// adapt: the last speculative call's results were (not) picked up
-					if (sc.hitsSince * 2 >= sc.ahead) sc.ahead = std::min(sc.ahead * 2, maxAhead);
-					else if (!kv.second.empty() && sc.hitsSince * 8 < sc.ahead) sc.ahead = std::max(sc.ahead / 2, 8u);
-					sc.hitsSince = 0;
+					// adapt over windows of a few calls (results are picked up over the calls that follow theirs): the
+					// records computed ahead were (not) asked for
+					if (sc.computedSince >= 2 * (uint64_t)sc.ahead)
+					{
+						if (sc.hitsSince * 2 >= sc.computedSince) sc.ahead = std::min(sc.ahead * 2, maxAhead);
+						else if (sc.hitsSince * 8 < sc.computedSince) sc.ahead = std::max(sc.ahead / 2, 8u);
+						sc.hitsSince = 0; sc.computedSince = 0;
+					}
 					sc.wanted = false;
 					const uint32_t base = qNFwd ? qFirstId : firstId, cnt = qNFwd ? qNFwd : nFwd;
 					std::vector<uint32_t>& ids = aheadIds[kv.first];
@@ -244,6 +282,29 @@ void fgb_container::run()
 							if (sc.ready.find(id) == sc.ready.end()) { ids.push_back(id); ++added; }
 						}
 						if (added) sc.frontier[strand] = id;
+						sc.computedSince += added;
+					}
+					// neighbours of the reads handed out so far (lazy class only)
+					if (std::get<0>(kv.first) == 0 && !std::get<1>(kv.first))
+					{
+						if (sc.computedNbSince >= 4 * (uint64_t)sc.aheadNb)
+						{
+							if (sc.hitsNbSince * 8 >= sc.computedNbSince) sc.aheadNb = std::min(sc.aheadNb * 2, maxAhead);
+							else if (sc.hitsNbSince * 64 < sc.computedNbSince) sc.aheadNb = std::max(sc.aheadNb / 2, 8u);
+							sc.hitsNbSince = 0; sc.computedNbSince = 0;
+						}
+						nbStart[kv.first] = ids.size();
+						uint32_t added = 0;
+						while (added < sc.aheadNb && !sc.neighbours.empty())
+						{
+							const uint32_t id = sc.neighbours.front(); sc.neighbours.pop_front();
+							bool asked = false;
+							for (QuickReq* r : kv.second) asked |= r->id == id;
+							if (asked || sc.ready.find(id) != sc.ready.end()) continue;
+							if (std::find(ids.begin(), ids.end(), id) != ids.end()) continue;
+							ids.push_back(id); ++added;
+						}
+						sc.computedNbSince += added;
 					}
 				}
 			const fg_detector_params p = params;
@@ -307,10 +368,12 @@ void fgb_container::run()
 				{
 					SpecClass& sc = spec[std::make_pair(std::get<0>(kv.first), std::get<1>(kv.first))];
 					const std::vector<uint32_t>& ids = aheadIds[kv.first];
+					const size_t nb0 = nbStart.count(kv.first) ? nbStart[kv.first] : ids.size();
 					for (size_t i = 0; i < kv.second.size(); ++i)
 					{
-						sc.ready[ids[i]] = std::move(kv.second[i]);
+						sc.ready[ids[i]] = SpecEntry{std::move(kv.second[i]), (uint8_t)(i >= nb0 ? 1 : 0)};
 						sc.order.push_back(ids[i]);
+						sc.seen[ids[i]] = 1;
 					}
 					while (sc.ready.size() > 2 * (size_t)maxAhead && !sc.order.empty())
 					{
@@ -318,6 +381,20 @@ void fgb_container::run()
 						sc.order.pop_front();
 					}
 					while (sc.order.size() > 4 * (size_t)maxAhead) sc.order.pop_front();
+				}
+			// the records on the other side of the overlaps just handed out (lazy class): next call's neighbours
+			if (maxAhead)
+				for (auto& kv : classes)
+				{
+					if (std::get<0>(kv.first) != 0 || std::get<1>(kv.first) || std::get<2>(kv.first)) continue;
+					SpecClass& sc = spec[std::make_pair(0, (uint8_t)0)];
+					for (QuickReq* r : kv.second)
+					{
+						if (r->status != FG_OK || !r->res) continue;
+						sc.seen[r->id] = 1;
+						queueNeighbours(sc, r->res->recs);
+					}
+					if (sc.seen.size() > 64 * (size_t)maxAhead + 4 * (size_t)(qNFwd ? qNFwd : nFwd)) sc.seen.clear();
 				}
 			divStats.insert(divStats.end(), allSt.begin(), allSt.end());
 			cvDone.notify_all();
@@ -344,10 +421,12 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 			auto it = sc.ready.find(r.id);
 			if (it != sc.ready.end())
 			{
-				r.res = std::move(it->second);
+				r.res = std::move(it->second.res);
+				if (it->second.origin) ++sc.hitsNbSince; else ++sc.hitsSince;
 				sc.ready.erase(it);
-				++sc.hitsSince; ++c->stats.ahead_hits;
+				++c->stats.ahead_hits;
 				c->divStats.insert(c->divStats.end(), r.res->stats.begin(), r.res->stats.end());
+				if (r.maxOverlaps == 0 && !r.forceLocal) c->queueNeighbours(sc, r.res->recs);	// what the caller asks for next
 				// keep the device ahead of the callers: top up when half of the last call's results are gone
 				if (!sc.wanted && sc.ready.size() * 2 < sc.ahead) { sc.wanted = true; c->cvWork.notify_one(); }
 				r.done = true; r.status = FG_OK;

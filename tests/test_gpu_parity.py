@@ -414,6 +414,69 @@ def test_bridge_read_ahead(built):
     oc.close()
 
 
+def test_bridge_neighbour_read_ahead(built):
+    """Extender's way of asking (extender.cpp:44-98): the overlaps of the current read, then the reads on the other
+    side of them, longest overlap first, a few of them, then on to one of those.  The scheduler computes the records
+    named by the overlaps it hands out ahead of their requests; lists stay the direct ones and most requests of the
+    walk are answered without a device call of their own."""
+    import threading
+    from flye_amd import config, gpu, synth
+    rs = synth.simulate(seed=41, genome_len=600_000, coverage=30, kind="pb_raw").filter_min_len(1000)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = 0.3
+    allq = np.arange(0, 2 * rs.n, dtype=np.uint32)
+    direct = det.getSeqOverlapsBatch(allq)
+    oc = gpu.BatchingOverlapContainer(det, max_batch=64, linger_us=100)
+    errors = []
+    asked = [0]
+    cache, cache_lock = {}, threading.Lock()    # OverlapContainer's own cache sits above the seam, shared by its threads:
+                                                # a read reaches getSeqOverlaps once
+
+    def extend(start, steps):
+        try:
+            def lazy(fid):
+                with cache_lock:
+                    have = cache.get(fid)
+                    if have is None:
+                        asked[0] += 1
+                if have is None:
+                    have = oc.quickSeqOverlaps(fid, 0, False)
+                    assert have.tobytes() == direct.of(fid).tobytes(), fid
+                    with cache_lock:
+                        cache[fid] = have
+                return have
+            cur = start
+            visited = {cur & ~1}
+            for _ in range(steps):
+                ov = lazy(cur & ~1)
+                cand = ov[np.argsort(-(ov["cur_end"] - ov["cur_begin"]), kind="stable")]
+                fresh = [int(o["ext_id"]) for o in cand if (int(o["ext_id"]) & ~1) not in visited]
+                nxt = None
+                for e in fresh[:4]:             # the first few candidates are looked at, the first usable one is taken
+                    if len(lazy(e & ~1)) and nxt is None:
+                        nxt = e
+                if nxt is None:
+                    return
+                visited.add(nxt & ~1)
+                cur = nxt
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=extend, args=(int(s), 60)) for s in np.random.default_rng(2).choice(allq[::2], 6, replace=False)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    s1 = oc.stats()
+    oc.close()
+    assert asked[0] > 200
+    print("neighbour read-ahead:", asked[0], "reads asked for,", s1)
+    assert s1["ahead_hits"] > 0.5 * asked[0], (s1, asked[0])        # most reads of the walk were there already
+    assert s1["device_calls"] < 0.6 * asked[0], (s1, asked[0])
+
+
 def test_internal_chunking_is_invisible(built, monkeypatch):
     """fg_overlaps cuts big batches into chunks bounded by k-mers / seed hits (and halves a
     chunk whose hits exceed the budget); results must not depend on the cut."""
