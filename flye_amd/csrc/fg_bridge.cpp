@@ -110,6 +110,7 @@ struct fgb_container {
 	fgb_stats stats{0, 0, 0, 0, 0, 0, 0};
 	bool stop = false;
 	std::thread worker;
+	double tDevice = 0, tConvert = 0;	// dispatcher: seconds inside fg_overlaps / turning batches into per-read results
 
 	void run();
 	int deviceCall(const fg_detector_params& p, const std::vector<uint32_t>& ids, int32_t mo, uint8_t fl,
@@ -156,7 +157,14 @@ int fgb_container::deviceCall(const fg_detector_params& p, const std::vector<uin
 							  std::vector<std::unique_ptr<ReadResult>>& out)
 {
 	fg_overlap_batch b;
+	const auto t0 = std::chrono::steady_clock::now();
 	const int rc = fg_overlaps(ctx, &p, ids.data(), (uint32_t)ids.size(), mo, fl, &b);
+	const auto t1 = std::chrono::steady_clock::now();
+	tDevice += std::chrono::duration<double>(t1 - t0).count();
+	if (getenv("FGB_TRACE") && atoi(getenv("FGB_TRACE")) > 1)
+		fprintf(stderr, "[fgb] call of %zu reads: %.2f ms (device %.2f ms), %llu records\n", ids.size(),
+				std::chrono::duration<double, std::milli>(t1 - t0).count(), rc == FG_OK ? b.device_seconds * 1e3 : 0.0,
+				rc == FG_OK ? (unsigned long long)b.n_recs : 0ULL);
 	if (rc != FG_OK) return rc;
 	out.resize(ids.size());
 	for (size_t i = 0; i < ids.size(); ++i)
@@ -175,6 +183,7 @@ int fgb_container::deviceCall(const fg_detector_params& p, const std::vector<uin
 		out[i] = std::move(r);
 	}
 	fg_release_batch(&b);
+	tConvert += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
 	return FG_OK;
 }
 
@@ -469,6 +478,10 @@ void fgb_destroy(fgb_container* c)
 	{ std::lock_guard<std::mutex> g(c->mu); c->stop = true; }
 	c->cvWork.notify_all();
 	if (c->worker.joinable()) c->worker.join();
+	if (getenv("FGB_TRACE"))
+		fprintf(stderr, "[fgb] %llu device calls, %llu reads (%llu ahead, %llu picked up): %.3f s in fg_overlaps, %.3f s per-read results\n",
+				(unsigned long long)c->stats.device_calls, (unsigned long long)c->stats.reads_computed,
+				(unsigned long long)c->stats.reads_ahead, (unsigned long long)c->stats.ahead_hits, c->tDevice, c->tConvert);
 	delete c;
 }
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -399,6 +400,8 @@ def run_ref(fasta, params_string=None, config=None, threads=8, min_read_len=0, m
     if partition_bad:
         cmd += ["--partition-bad", "1"]
     out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=env)
+    if os.environ.get("FLYE_REF_STDERR"):       # e.g. with FGB_TRACE=1: what the program wrote to stderr
+        sys.stderr.write(out.stderr)
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
