@@ -142,6 +142,9 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 #ifndef FIN_CAP_S
 #define FIN_CAP_S 256
 #endif		// <= : LDS, 4 groups per block; larger groups run on global scratch.
+#ifndef FIN_CAP_M
+#define FIN_CAP_M 1024	// LDS class of small calls (see fgChainStage)
+#endif
 #ifndef FIN_WAVES_S
 #define FIN_WAVES_S 1	// waves (= groups) per block of the <= 256-hit class / of the global-scratch class: one,
 					// so that a block's slot frees when ITS group is done (4 -> 1: 4.97 -> 4.46 and 5.83 -> 5.37 ms)
@@ -758,8 +761,10 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 						 c->dGroupLastCur.p, (i32)p->min_overlap, c->dListSmall.p, c->dListBig.p, (u32)PREP_CAP,
 						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
 	u32 nPrep[2];
-	HIP_CHECK(hipMemcpyAsync(nPrep, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
+	c->hScalar.reserve(8);
+	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
+	memcpy(nPrep, c->hScalar.p, 8);
 	if (!nPrep[0] && !nPrep[1]) return;
 	// Both stages below run their big-group class on the side stream beside the small-group class on the main
 	// one: the classes are disjoint sets of groups, and the big-group kernels end with a handful of waves on an
@@ -803,13 +808,18 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		join(sBig);
 	}
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
-	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : 4096u;
+	// A small call (a few hundred reads at most: what a caller thread's single request or the start of a read-ahead
+	// ramp looks like) is all latency: a handful of 257..1024-hit groups then sort and walk in LDS (20 KB per wave,
+	// which the bulk case cannot afford: occupancy) instead of on global scratch, ~1 ms off such a call.
+	const bool smallCall = (nPrep[0] + nPrep[1]) < 65536u && !getenv("FG_CHAIN_NO_SMALL_CALL");
+	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : (smallCall ? (u32)FIN_CAP_M : 4096u);
 	{ ScopedK t(c->timer, "k_dp_list");
 	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, hugeMin, c->dListSmall.p, c->dListDp.p,
 						 c->dListBig.p, c->dListCnt.p); }
 	u32 hc[4];
-	HIP_CHECK(hipMemcpyAsync(hc, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
+	memcpy(hc, c->hScalar.p, 16);
 	const u32* lists[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};	// <= 256 hits, <= hugeMin, more
 	// three independent chains of two kernels: the <= 256-hit groups on the main stream, the two classes of
 	// larger groups (few groups, long serial work per wave) beside them on side streams
@@ -832,9 +842,17 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		hipStream_t on = cls == 2 ? sHuge : sMid;
 		{ ScopedK t(c->timer, "k_chain_dp", on);
 		  hipLaunchKernelGGL(k_chain_dp, (hc[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, on, DP_ARGS(cls)); }
-		{ ScopedK t(c->timer, "k_chain_finish<global>", on);
-		  hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc[cls] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, on,
-							 FIN_ARGS(cls)); }
+		if (cls == 1 && smallCall && hugeMin <= (u32)FIN_CAP_M)
+		{
+			ScopedK t(c->timer, "k_chain_finish<lds1024>", on);
+			hipLaunchKernelGGL((k_chain_finish<FIN_CAP_M, 1>), hc[cls], 64, FIN_CAP_M * 20, on, FIN_ARGS(cls));
+		}
+		else
+		{
+			ScopedK t(c->timer, "k_chain_finish<global>", on);
+			hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc[cls] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, on,
+							   FIN_ARGS(cls));
+		}
 	}
 	if (hc[0])
 	{

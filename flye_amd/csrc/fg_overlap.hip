@@ -704,9 +704,12 @@ __global__ void k_chain_matches(const PrimRec* __restrict__ prims, u64 nPrim, co
 template <class T>
 T fetchScalar(fg_ctx* c, const T* dptr)
 {
-	T v;
-	HIP_CHECK(hipMemcpyAsync(&v, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
+	static_assert(sizeof(T) <= 8, "scalar");
+	c->hScalar.reserve(8);
+	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, dptr, sizeof(T), hipMemcpyDeviceToHost, c->stream));
 	HIP_CHECK(hipStreamSynchronize(c->stream));
+	T v;
+	memcpy(&v, c->hScalar.p, sizeof(T));
 	return v;
 }
 
@@ -739,8 +742,10 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	u32 cnt[3];
 	auto fetchCounts = [&]()
 	{
-		HIP_CHECK(hipMemcpyAsync(cnt, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
+		c->hScalar.reserve(8);
+		HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
+		memcpy(cnt, c->hScalar.p, 12);
 	};
 	fetchCounts();
 	u32 nBig = cnt[0], nWide = cnt[2];
@@ -971,9 +976,10 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	  HIP_CHECK(hipEventRecord(c->evOff, s));
 	  // the records in pieces, an event behind each: the caller does not wait for them here (the host shim's
 	  // threads wait for the piece they read)
+	  const int nPieces = nPrim >= 100000 ? FG_D2H_PIECES : 1;	// a small result is one copy (the unused events are recorded all the same)
 	  for (int i = 0; i < FG_D2H_PIECES; ++i)
 	  {
-		  const u64 a = nPrim * i / FG_D2H_PIECES, b = nPrim * (i + 1) / FG_D2H_PIECES;
+		  const u64 a = i < nPieces ? nPrim * i / nPieces : nPrim, b = i < nPieces ? nPrim * (i + 1) / nPieces : nPrim;
 		  if (b > a)
 			  HIP_CHECK(hipMemcpyAsync(c->hPrim.p + (primBase + a) * sizeof(PrimRec), c->dPrimOut.p + a * sizeof(PrimRec),
 									   (b - a) * sizeof(PrimRec), hipMemcpyDeviceToHost, s));
