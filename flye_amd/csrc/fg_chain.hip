@@ -647,7 +647,10 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 			const int l = __ffsll((long long)m) - 1;
 			m &= m - 1;
 			const i32 start = __builtin_amdgcn_readlane(st, __builtin_amdgcn_readfirstlane(l));
-			if (lane == 0 && back[start] != -1)
+			// every start still in m is alive: the mask is screened again after each walk (the 64 starts of a
+			// batch are mostly the upper elements of ONE chain -- its scores rise along it -- and the walk from
+			// its tip consumes them all: one parallel look instead of one lane-0 look per dead start)
+			if (lane == 0)
 			{
 				i32 firstM = 0, chainLength = 0, pos = start;
 				while (pos != -1)
@@ -667,6 +670,12 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 					if (ncand == 0 || c4.w > best.w) best = c4;	// <= 16 candidates: insertion sort = stable
 					++ncand;
 				}
+			}
+			if (m)
+			{
+				wsort::wave_mem_fence();
+				const i32 bk2 = in ? back[st] : -1;
+				m &= __builtin_amdgcn_ballot_w64(bk2 != -1);
 			}
 		}
 	}
