@@ -1036,11 +1036,13 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		if (p->partition_bad_mappings) { own->needsTrim.assign(1, 0); out->needs_trim = own->needsTrim.data(); }
 		return;
 	}
+#ifdef FG_SORT_ABLATE
 	if (getenv("FG_ABLATE"))
 	{
 		const int ab = atoi(getenv("FG_ABLATE"));
 		HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(wsort::g_ablate), &ab, sizeof(int)));
 	}
+#endif
 
 	// The batch is cut into chunks so that the per-chunk scratch (8 B per query k-mer,
 	// ~70 B per seed hit) stays bounded whatever the caller passes; a chunk whose hits

@@ -20,9 +20,16 @@
 
 namespace wsort {
 
-// timing experiments only (FG_ABLATE env): 16 = skip the register quicksort phase of
-// sort_small, 32 = skip its final placement, 64 = skip partition pass B
+// timing experiments only (build with -DFG_SORT_ABLATE, then FG_ABLATE env): 16 = skip the register quicksort
+// phase of sort_small, 32 = skip its final placement, 64 = skip partition pass B.  Compiled out otherwise: a
+// check is a scalar load of a global in the middle of a dependent chain, once per partition (measured: a
+// similar check in k_chain_dp's head loop cost 20 % of that kernel).
+#ifdef FG_SORT_ABLATE
 __device__ int g_ablate = 0;
+#define FG_SORT_ABLATED(bit) (g_ablate & (bit))
+#else
+#define FG_SORT_ABLATED(bit) false
+#endif
 
 template <class KT>
 struct KV { KT k; u32 v; };
@@ -145,7 +152,7 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	(void)stk;
 	while (true)
 	{
-		while (b - a > 16 && !(g_ablate & 16))
+		while (b - a > 16 && !FG_SORT_ABLATED(16))
 		{
 			if (d == 0)
 			{
@@ -188,7 +195,7 @@ __device__ __forceinline__ void sort_small(KT* K, u32* V, int first, int n, int 
 	// 15 lanes above).  Neighbours arrive by DPP wave rotations (no LDS traffic); the lane
 	// id travels with the key, so the count does not depend on the rotation direction.
 	int pos = lane;
-	if (!(g_ablate & 32))
+	if (!FG_SORT_ABLATED(32))
 	{
 		// Each pair of lanes at distance <= 15 is compared once: a copy of every element
 		// travels 15 lanes upwards; the lane it visits and the visitor both book the outcome
@@ -289,7 +296,7 @@ __device__ __forceinline__ int partition_big(KT* K, u32* V, int first, int last,
 	wave_mem_fence();
 	const int nPairs = cL < cR ? cL : cR;
 	int nSwap = 0;
-	for (int t2 = 0; t2 < ((g_ablate & 64) ? 0 : nPairs); t2 += 64)
+	for (int t2 = 0; t2 < (FG_SORT_ABLATED(64) ? 0 : nPairs); t2 += 64)
 	{
 		const int kq = t2 + lane;
 		const bool valid = kq < nPairs;
