@@ -354,6 +354,7 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 	const i32 FAR = -(1 << 30);
 	i32 pc = FAR, pe = FAR, ps = 0;		// previous tile
 	i32 ntc = lane < n ? (i32)cur[lane] : 0, nte = lane < n ? (i32)ext[lane] : 0;
+	asm volatile("" : "+v"(ntc), "+v"(nte));	// waited for here, so that no wait for them is left inside the loop (see its end)
 	for (i32 tb0 = 0; tb0 < n; tb0 += 64)
 	{
 		const i32 tc = ntc, te = nte;
@@ -446,6 +447,11 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 			ts = hl == il ? sNew + off : ts;	// the head (off = 0) and its run inside this tile
 			tbk = lane == il ? (maxScore > k ? maxId : -1) : tbk;
 		}
+		// The next tile's coordinates (loaded at the top of this iteration) are taken in HERE, before this tile's
+		// stores go out: the counter of outstanding memory operations retires in order, so a wait placed behind the
+		// stores (or behind the next prefetch, where the compiler puts it by itself and then waits for everything
+		// because the loads sit in branches) would cost a full round trip per tile.
+		asm volatile("" : "+v"(ntc), "+v"(nte));
 		if (valid)
 		{
 			score[tb0 + lane] = ts; back[tb0 + lane] = tbk;
