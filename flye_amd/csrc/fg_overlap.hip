@@ -161,6 +161,9 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 // together): key = record << curBits | curPos -- same order, a third less sort traffic.
 // KT = PK: one 64-bit record per hit (fg_ctx.h), no value array.  Consumers read any of the
 // three through HitKeyView<KT>.
+#ifndef FILL_ITEMS
+#define FILL_ITEMS 4
+#endif
 template <class KT>
 __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
 					   const u64* __restrict__ qKmerOff, int k, u32 firstId, int curBits,
@@ -168,10 +171,13 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 					   const u64* __restrict__ hitOff, const u64* __restrict__ filtOff,
 					   KT* __restrict__ hitKey, u32* __restrict__ hitVal, i32* __restrict__ filtPos)
 {
+	// FILL_ITEMS consecutive positions per thread and step: a step is a chain of barriers, LDS searches and
+	// dependent loads (~4 us whatever it carries), and a read of 10^4 positions took 40 of them at one position per
+	// thread
+	constexpr int FI = FILL_ITEMS;
 	__shared__ u32 sh[WG / 64 + 1];
-	__shared__ u32 sStart[WG + 1];
-	__shared__ u64 sOff[WG];
-	__shared__ u32 sSelf[WG];	// 1: the list holds this position's own (trivial) entry
+	__shared__ u32 sStart[WG * FI + 1];
+	__shared__ u64 sOff[WG * FI];		// list offset | FLAG_FLIP | FLAG_SELF (the list holds this position's own, trivial entry)
 	const u32 q = blockIdx.x;
 	const u32 rec = query[q];
 	const i32 L = qLen[rec >> 1];
@@ -179,38 +185,52 @@ __global__ void k_fill(const u32* __restrict__ query, const i32* __restrict__ le
 	const u64* pr = probe + qKmerOff[q];
 	u64 hbase = hitOff[q];
 	u64 fbase = filtOff[q];
-	for (i32 p0 = 0; p0 < nk; p0 += WG)
+	for (i32 p0 = 0; p0 < nk; p0 += WG * FI)
 	{
-		const i32 p = p0 + threadIdx.x;
-		const u64 v = p < nk ? pr[p] : 0;
-		u32 cnt = (u32)(v & FG_CNT_MASK);
-		const bool rep = (cnt == FG_CNT_REPETITIVE);
-		if (rep) cnt = 0;
-		const bool flip = v & FLAG_FLIP;
-		const u64 off = (v >> FG_CNT_BITS) & OFF_MASK;
-		// the trivial self hit is dropped in the output walk below (no search here: a per-position
-		// binary search of the list put log2(cnt) dependent loads on every step of the block)
-		const bool hasSelf = cnt && (v & FLAG_SELF);
-		const u32 eff = cnt - (hasSelf ? 1u : 0u);
+		u64 vv[FI];
+		u32 eff[FI];
+		u32 effSum = 0, repSum = 0;
+#pragma unroll
+		for (int i = 0; i < FI; ++i)
+		{
+			const i32 p = p0 + (i32)threadIdx.x * FI + i;
+			const u64 v = p < nk ? pr[p] : 0;
+			u32 cnt = (u32)(v & FG_CNT_MASK);
+			const bool rep = (cnt == FG_CNT_REPETITIVE);
+			if (rep) cnt = 0;
+			// the trivial self hit is dropped in the output walk below (no search here: a per-position
+			// binary search of the list put log2(cnt) dependent loads on every step of the block)
+			const bool hasSelf = cnt && (v & FLAG_SELF);
+			eff[i] = cnt - (hasSelf ? 1u : 0u);
+			vv[i] = (((v >> FG_CNT_BITS) & OFF_MASK) | (v & FLAG_FLIP) | (hasSelf ? FLAG_SELF : 0ULL));
+			if (rep) { vv[i] = ~0ULL; ++repSum; }		// marks a repetitive position (no list)
+			effSum += eff[i];
+		}
 		u32 tot, ftot;
-		const u32 start = block_exscan(eff, sh, &tot);
-		const u32 fstart = block_exscan(rep ? 1u : 0u, sh, &ftot);
-		if (rep) filtPos[fbase + fstart] = p;
-		sStart[threadIdx.x] = start;
-		sOff[threadIdx.x] = off | (flip ? FLAG_FLIP : 0ULL);
-		sSelf[threadIdx.x] = hasSelf ? 1u : 0u;
-		if (threadIdx.x == 0) sStart[WG] = tot;
+		u32 start = block_exscan(effSum, sh, &tot);
+		u32 fstart = block_exscan(repSum, sh, &ftot);
+#pragma unroll
+		for (int i = 0; i < FI; ++i)
+		{
+			const i32 p = p0 + (i32)threadIdx.x * FI + i;
+			const bool rep = vv[i] == ~0ULL;
+			if (rep) filtPos[fbase + fstart++] = p;
+			sStart[threadIdx.x * FI + i] = start;
+			sOff[threadIdx.x * FI + i] = rep ? 0ULL : vv[i];
+			start += eff[i];
+		}
+		if (threadIdx.x == 0) sStart[WG * FI] = tot;
 		__syncthreads();
 		for (u32 o = threadIdx.x; o < tot; o += WG)
 		{
 			// owner = last t with sStart[t] <= o (it has a non-empty list)
-			u32 lo = 0, hi = WG;
+			u32 lo = 0, hi = WG * FI;
 			while (hi - lo > 1) { const u32 m = (lo + hi) >> 1; if (sStart[m] <= o) lo = m; else hi = m; }
 			const u32 t = lo;
 			const u32 j = o - sStart[t];
 			const u64 so = sOff[t];
 			u64 e = entries[(so & OFF_MASK) + j];
-			if (sSelf[t])
+			if (so & FLAG_SELF)
 			{
 				// no trivial matches (overlap.cpp:188-190): the list is ascending and holds this
 				// position's own entry exactly once; output j is entry j before it, entry j + 1 after
