@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--cpu-reference-bp", type=float, default=250e6,
                     help="query prefix (bp) the reference's overlap stage is timed on")
     ap.add_argument("--cpu-reference-threads", type=int, default=0, help="0 = the CPUs this process may use")
+    ap.add_argument("--no-assemble-stage", action="store_true",
+                    help="skip the reference's whole `flye-modules assemble` stage (pure, and with the device seams)")
     args = ap.parse_args()
 
     import torch
@@ -243,6 +245,10 @@ def main():
             if not args.no_cpu_reference:
                 ref = cpu_reference(rs, preset, det_min_ovlp, queries, res,
                                     args.cpu_reference_threads or effective_cpus(), args.cpu_reference_bp)
+                if ref is not None and "error" not in ref and not args.no_assemble_stage:
+                    # (the program builds its own index on this GPU beside the bench's: both fit)
+                    ref["reference_program_with_device_seams_assemble"] = assemble_stage(
+                        rs, preset, min_ovlp, args.cpu_reference_threads or effective_cpus())
             if ref is not None and "error" not in ref:
                 # the reference itself (Flye's own code on this host's cores) is THE cpu baseline;
                 # the port (oracle/) is reported beside it
@@ -365,6 +371,38 @@ def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=250e6)
             "sample": f"first {n} forward reads ({info['queried_bp']} bp) of the same workload through the reference's "
                       f"processInParallel on {threads} threads; index built by the reference over all reads; "
                       f"{wall:.1f} s wall in total", "gpu_records_identical_to_reference": same}
+
+
+def assemble_stage(rs, preset, min_ovlp, threads):
+    """The reference's whole assemble stage (`flye-modules assemble`, main_assemble.cpp:123-257: reads -> index ->
+    estimateOverlaperParameters -> Extender::assembleDisjointigs with ChimeraDetector -> ConsensusGenerator ->
+    draft_assembly.fasta) on the bench reads, twice: compiled from the reference alone (oracle/_ref/flye_assemble)
+    and with the device seams linked in front (oracle/_ref/flye_assemble_gpu).  Same FASTA, cfg, --min-ovlp and
+    thread count.  With more than one thread the disjointigs depend on thread timing in the reference itself
+    (extender.cpp:269), so the two drafts are compared by size only; byte identity at one thread is
+    tests/test_seam.py's."""
+    import tempfile
+    from flye_amd import config
+    from oracle import oracle as O
+    if not (O.have_assemble() and O.have_assemble_gpu()):
+        return {"error": "oracle/_ref/flye_assemble(_gpu) not built"}
+    out = {"threads": threads, "min_ovlp": int(min_ovlp)}
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, "reads.fasta")
+        rs.write_fasta(fa)
+        cfgp = config.write_cfg(os.path.join(tmp, "asm.cfg"), preset)
+        for name, binary in (("device_seams", O.FLYE_ASSEMBLE_GPU), ("reference", O.FLYE_ASSEMBLE)):
+            draft = os.path.join(tmp, name + ".fasta")
+            try:
+                info = O.run_assemble(fa, cfgp, draft, threads=threads, min_ovlp=min_ovlp, binary=binary)
+                data = open(draft, "rb").read()
+                out[name] = {"wall_s": round(info["wall_s"], 2), "extend_s_log": info.get("extend_s_log"),
+                             "draft_bytes": len(data), "disjointigs": data.count(b">")}
+                if "seams" in info and name == "device_seams":
+                    out[name]["seams"] = info["seams"]
+            except Exception as e:  # noqa: BLE001
+                out[name] = {"error": str(e)[:300]}
+    return out
 
 
 def records_equal_ref_file(recs, path) -> bool:

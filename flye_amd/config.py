@@ -23,6 +23,21 @@ _COMMON = {
     "maximum_jump": 1500,
 }
 
+# what the callers of the path in the assemble stage read besides the presets: Extender / ChimeraDetector
+# (reference src/assemble/extender.cpp, chimera.cpp; values flye/config/bin_cfg/asm_defaults.cfg:8-13 and the
+# per-read-type files' low_cutoff_warning / add_unassembled_reads).  Only used to write a cfg file for the
+# reference's own `flye-modules assemble` program when it runs over the device seams (tests, bench).
+ASSEMBLE_STAGE = {
+    "max_coverage_drop_rate": 5, "max_extensions_drop_rate": 5, "chimera_window": 100,
+    "min_reads_in_disjointig": 4, "max_inner_reads": 10, "max_inner_fraction": 0.25,
+}
+ASSEMBLE_STAGE_BY_PRESET = {
+    "raw": {"low_cutoff_warning": 1, "add_unassembled_reads": 0},
+    "corrected": {"low_cutoff_warning": 0, "add_unassembled_reads": 0},
+    "hifi": {"low_cutoff_warning": 0, "add_unassembled_reads": 0},
+    "subasm": {"low_cutoff_warning": 0, "add_unassembled_reads": 1},
+}
+
 PRESETS = {
     "raw": dict(_COMMON, kmer_size=17, use_minimizers=0, minimizer_window=0,
                 reads_base_alignment=0, assemble_kmer_sample=1,
@@ -64,6 +79,27 @@ def params_string(name: str) -> str:
     (``config.h:84-96``) -- lets the test-side reference dumper run without cfg files."""
     return ",".join(f"{k}={v!r}" if isinstance(v, float) else f"{k}={v}"
                     for k, v in PRESETS[name].items())
+
+
+def assemble_stage(name: str) -> dict:
+    """Every key `flye-modules assemble` reads (main_assemble.cpp, extender.cpp, chimera.cpp, overlap.cpp,
+    vertex_index.cpp) for read type ``name``."""
+    d = dict(PRESETS[name])
+    d.update(ASSEMBLE_STAGE)
+    d.update(ASSEMBLE_STAGE_BY_PRESET[name])
+    return d
+
+
+def write_cfg(path: str, name: str, extra: dict | None = None) -> str:
+    """A flat ``key = value`` file in the format Config::load parses (config.h:36-72) holding
+    ``assemble_stage(name)``: the --config argument of the reference's assemble program."""
+    d = assemble_stage(name)
+    if extra:
+        d.update(extra)
+    with open(path, "w") as f:
+        for k, v in d.items():
+            f.write(f"{k} = {v!r}\n" if isinstance(v, float) else f"{k} = {v}\n")
+    return path
 
 
 def min_overlap_from_reads(lengths, read_type="raw", meta=False) -> int:

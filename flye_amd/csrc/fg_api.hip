@@ -8,6 +8,7 @@
 #include <new>
 
 #include <mutex>
+#include <atomic>
 
 static std::mutex g_poolMutex;
 static std::vector<BatchOwner*> g_pool;
@@ -37,10 +38,17 @@ namespace {
 // chimera.cpp:76) and never seeds it, so a host program that creates a context first would see other
 // picks.  While this guard lives the process draws from a private state array; the caller's stream
 // continues exactly where it was (glibc keeps the position inside the state array it hands back).
+// Only the FIRST fg_create of a process takes the guard (later ones initialise nothing that draws), and swapping
+// glibc's process-wide state is not thread safe: that first call must come from a thread beside which no other
+// thread uses rand() -- in Flye the main thread building the index (flye_gpu.h, fg_create).
 struct RandStreamGuard {
 	char buf[128];
-	char* old;
-	RandStreamGuard() { old = initstate(1u, buf, sizeof(buf)); }
+	char* old = nullptr;
+	RandStreamGuard()
+	{
+		static std::atomic<bool> firstDone{false};
+		if (!firstDone.exchange(true)) old = initstate(1u, buf, sizeof(buf));
+	}
 	~RandStreamGuard() { if (old) setstate(old); }
 };
 
@@ -434,8 +442,11 @@ int fg_align_cigar_ksw(fg_ctx* c, uint32_t n_pairs, const uint8_t* trg, const ui
 		}
 		std::vector<std::vector<uint8_t>> tOps(nThreads);
 		std::vector<std::vector<int32_t>> tLens(nThreads);
+		std::atomic<int> workerFailed{0};		// no exception may leave a pool thread
 		c->shimPool.run(nThreads, [&](unsigned th)
 		{
+		  try
+		  {
 			// thread-local vectors (the headers of tOps[] sit next to each other: appending through them would
 			// bounce one cache line between all threads), handed over at the end
 			std::vector<uint8_t> ops;
@@ -470,7 +481,10 @@ int fg_align_cigar_ksw(fg_ctx* c, uint32_t n_pairs, const uint8_t* trg, const ui
 				own->err[i] = float(numMiss + numIndels) / std::max(trgLen, qryLen);
 			}
 			tOps[th].swap(ops); tLens[th].swap(lens);
+		  }
+		  catch (...) { workerFailed.store(1); }
 		});
+		if (workerFailed.load()) throw std::bad_alloc();
 		for (u32 i = 0; i < n_pairs; ++i) own->runOff[i + 1] += own->runOff[i];
 		own->ops.reserve(own->runOff[n_pairs]); own->lens.reserve(own->runOff[n_pairs]);
 		for (unsigned th = 0; th < nThreads; ++th)

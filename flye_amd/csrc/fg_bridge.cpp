@@ -92,8 +92,23 @@ struct SpecClass {
 
 } // namespace
 
+// An fg_ctx serves one host thread at a time (flye_gpu.h).  Several containers may sit on one context -- two
+// detectors with different parameters over one VertexIndex -- and each has its own dispatcher thread: their device
+// calls (fg_set_queries .. fg_overlaps .. fg_set_queries) take turns through one mutex per context.
+static std::shared_ptr<std::mutex> contextMutex(fg_ctx* ctx)
+{
+	static std::mutex regMu;
+	static std::map<fg_ctx*, std::weak_ptr<std::mutex>> reg;
+	std::lock_guard<std::mutex> g(regMu);
+	for (auto it = reg.begin(); it != reg.end();) { if (it->second.expired()) it = reg.erase(it); else ++it; }
+	std::shared_ptr<std::mutex> m = reg[ctx].lock();
+	if (!m) { m = std::make_shared<std::mutex>(); reg[ctx] = m; }
+	return m;
+}
+
 struct fgb_container {
 	fg_ctx* ctx = nullptr;
+	std::shared_ptr<std::mutex> ctxMu;	// shared by every container on this context
 	fg_detector_params params;
 	uint32_t maxBatch = 4096, lingerUs = 200;
 	uint32_t firstId = 0, nFwd = 0, qFirstId = 0, qNFwd = 0;	// id ranges of the context's containers
@@ -217,7 +232,8 @@ void fgb_container::run()
 			const fg_detector_params p = params;
 			lk.unlock();
 			std::vector<std::unique_ptr<ReadResult>> res;
-			const int rc = deviceCall(p, ids, 0, 0, res);
+			int rc;
+			{ std::lock_guard<std::mutex> ctxTurn(*ctxMu); rc = deviceCall(p, ids, 0, 0, res); }
 			std::vector<RecList> revs(rc == FG_OK ? ids.size() : 0);
 			std::vector<float> st;
 			for (size_t i = 0; i < revs.size(); ++i)
@@ -327,6 +343,7 @@ void fgb_container::run()
 				std::vector<QuickReq*>& reqs = kv.second;
 				std::vector<uint32_t> qids;
 				int rc = FG_OK;
+				std::lock_guard<std::mutex> ctxTurn(*ctxMu);
 				if (foreign)
 				{
 					// the waiting foreign records become a temporary query container; their device ids
@@ -458,7 +475,7 @@ int fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params
 	try
 	{
 		std::unique_ptr<fgb_container> c(new fgb_container);
-		c->ctx = ctx; c->params = *params;
+		c->ctx = ctx; c->ctxMu = contextMutex(ctx); c->params = *params;
 		c->maxBatch = max_batch ? max_batch : 4096;
 		c->lingerUs = linger_us;
 		if (getenv("FGB_READ_AHEAD")) c->maxAhead = (uint32_t)std::max(0, atoi(getenv("FGB_READ_AHEAD")));

@@ -47,7 +47,12 @@ enum {
 typedef struct fg_ctx fg_ctx;
 
 /* Parameters::get().kmerSize (src/common/config.h:103-115) is process-global
- * in the reference; here it is a property of the context. */
+ * in the reference; here it is a property of the context.
+ * The FIRST fg_create of a process initialises the HIP runtime, which draws from libc's rand() stream; the
+ * call parks the caller's stream in a private state array for that time (initstate / setstate) so that the
+ * reference's own rand() consumers (overlap.cpp:752-756, chimera.cpp:76, sequence_container.cpp:318-328) see
+ * the numbers they would have seen.  That swap is process-wide: make the first fg_create from a thread
+ * beside which no other thread calls rand() (Flye: the main thread, at index build).  Later calls swap nothing. */
 int  fg_create(fg_ctx** out, int device, int kmer_size);
 void fg_destroy(fg_ctx* ctx);
 const char* fg_strerror(int code);

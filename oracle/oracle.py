@@ -428,3 +428,77 @@ def parse_ref_index(path, rs):
     pos = g - rec_off[rec.astype(np.int64)]
     return header, IndexExport(np.array(keys, np.uint64), np.array(off, np.uint64),
                                (rec << np.uint64(32)) | pos, np.array(rep, np.uint64))
+
+
+# --- the reference's own assemble stage -------------------------------------------------------
+FLYE_ASSEMBLE = os.path.join(_HERE, "_ref", "flye_assemble")            # main_assemble.cpp:123-257, compiled unmodified
+FLYE_ASSEMBLE_GPU = os.path.join(_HERE, "_ref", "flye_assemble_gpu")    # the same objects behind integration/flye_seam.o
+
+
+def have_assemble() -> bool:
+    return os.path.exists(FLYE_ASSEMBLE)
+
+
+def have_assemble_gpu() -> bool:
+    return os.path.exists(FLYE_ASSEMBLE_GPU)
+
+
+def _log_stage_seconds(log_text):
+    """wall-clock marks of the stage's log lines ([YYYY-MM-DD hh:mm:ss], one-second resolution)"""
+    import datetime
+    import re
+    marks = {}
+    for line in log_text.splitlines():
+        m = re.match(r"\[(\d{4}-\d\d-\d\d \d\d:\d\d:\d\d)\] (\w+): (.*)", line)
+        if m:
+            t = datetime.datetime.strptime(m.group(1), "%Y-%m-%d %H:%M:%S").timestamp()
+            for key, pat in (("read", "Reading sequences"), ("extend", "Extending reads"),
+                             ("assembled", "Assembled "), ("consensus", "Generating sequence"), ("write", "Writing FASTA")):
+                if m.group(3).startswith(pat) and key not in marks:
+                    marks[key] = t
+    return marks
+
+
+def run_assemble(fasta, cfg_path, out_fasta, threads=1, min_ovlp=5000, binary=None, env=None, log_path=None):
+    """`flye-modules assemble --reads .. --out-asm .. --config .. --threads .. --min-ovlp ..` (the argv
+    flye/assembly/assemble.py:43-69 builds), by the pure reference program or the one with the device seams.
+    Returns wall seconds, the log's stage marks and, for the seam program, what the seams did
+    (FLYE_GPU_STATS, integration/flye_seam.cpp)."""
+    import time
+    log_path = log_path or out_fasta + ".log"
+    stats_path = out_fasta + ".seam.json"
+    e = dict(os.environ if env is None else env)
+    e["FLYE_GPU_STATS"] = stats_path
+    cmd = [binary or FLYE_ASSEMBLE, "--reads", fasta, "--out-asm", out_fasta, "--config", cfg_path, "--log", log_path,
+           "--threads", str(threads), "--min-ovlp", str(min_ovlp), "--debug"]
+    t = time.perf_counter()
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True, env=e)
+    wall = time.perf_counter() - t
+    if os.environ.get("FLYE_REF_STDERR"):
+        sys.stderr.write(out.stderr)
+    info = {"wall_s": wall, "marks": _log_stage_seconds(open(log_path).read())}
+    m = info["marks"]
+    if "extend" in m and "consensus" in m:
+        info["extend_s_log"] = m["consensus"] - m["extend"]     # Extender::assembleDisjointigs, to the second
+    if os.path.exists(stats_path):
+        info["seams"] = json.load(open(stats_path))
+    return info
+
+
+def ref_consensus(pairs, threads=1, binary=None):
+    """ConsensusGenerator::generateConsensuses (consensus_generator.cpp:18-126) over two-read disjointigs, one
+    per (left, right) pair of 0..3 arrays, by the compiled reference (or the program with the device seams):
+    -> (stdout text: one "name sequence" line per pair, {"pairs", "threads", "consensus_s"})."""
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for a, b in pairs:
+            f.write("^" + "".join("ACGT"[x] for x in a) + " ^" + "".join("ACGT"[x] for x in b) + "\n")
+        path = f.name
+    try:
+        from flye_amd import config
+        out = subprocess.run([binary or REF_DUMPER, "--threads", str(threads), "--params", config.params_string("raw"),
+                              "--consensus-pairs", path], check=True, capture_output=True, text=True)
+    finally:
+        os.unlink(path)
+    info = json.loads([l for l in out.stderr.strip().splitlines() if l.startswith("{")][-1])
+    return out.stdout, info

@@ -46,6 +46,7 @@
 #include "common/parallel.h"
 #include "sequence/edlib.h"
 #include "sequence/alignment.h"
+#include "sequence/consensus_generator.h"
 #undef private
 #undef protected
 
@@ -105,6 +106,43 @@ int main(int argc, char** argv)
 				for (auto& c : cigar) printf(" %d%c", c.len, c.op);
 				printf("\n");
 			}
+			return 0;
+		}
+		else if (a == "--consensus-pairs")
+		{
+			// ConsensusGenerator::generateConsensuses (consensus_generator.cpp:18-126) over two-read "disjointigs":
+			// every line of the file is one (left read, right read) pair overlapping over their whole length, i.e. one
+			// getAlignmentCigarKsw + decodeCigar + switch-position search per pair, handed out over --threads worker
+			// threads (give --threads BEFORE this flag).  Prints every consensus sequence; the time goes to stderr.
+			std::ifstream in(next());
+			std::string qa, qb;
+			std::vector<ContigPath> contigs;
+			while (in >> qa >> qb)
+			{
+				qa.erase(0, 1); qb.erase(0, 1);
+				ContigPath path;
+				path.name = "pair_" + std::to_string(contigs.size());
+				path.sequences.push_back(DnaSequence(qa));
+				path.sequences.push_back(DnaSequence(qb));
+				OverlapRange ovlp(FastaRecord::ID_NONE, FastaRecord::ID_NONE, 0, 0, (int32_t)qa.size(), (int32_t)qb.size());
+				ovlp.curEnd = (int32_t)qa.size(); ovlp.extEnd = (int32_t)qb.size();
+				path.overlaps.push_back(ovlp);
+				contigs.push_back(path);
+			}
+			if (!params.empty()) Config::addParameters(params);	// give --params BEFORE this flag (maximum_jump is read)
+			Parameters::get().numThreads = threads;
+			Parameters::get().kmerSize = 17;
+			ConsensusGenerator gen;
+			{
+				// untimed warm-up on two pairs (a program with device seams starts its runtime here)
+				std::vector<ContigPath> warm(contigs.begin(), contigs.begin() + std::min<size_t>(2, contigs.size()));
+				gen.generateConsensuses(warm, false);
+			}
+			auto t0 = std::chrono::steady_clock::now();
+			auto recs = gen.generateConsensuses(contigs, false);
+			const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			for (auto& r : recs) printf("%s %s\n", r.description.c_str(), r.sequence.str().c_str());
+			fprintf(stderr, "{\"pairs\": %zu, \"threads\": %d, \"consensus_s\": %.6f}\n", contigs.size(), threads, sec);
 			return 0;
 		}
 		else if (a == "--edlib-pairs")

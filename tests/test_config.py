@@ -31,6 +31,23 @@ def test_presets_equal_reference_cfg_files(name):
         assert ref[k] == v, (name, k, ref[k], v)
 
 
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("name", ["raw", "corrected", "hifi", "subasm"])
+def test_assemble_stage_cfg_equals_reference_cfg_files(name, tmp_path):
+    """the cfg file written for the reference's assemble program holds the reference's values for every
+    key that program reads"""
+    from flye_amd import config
+    ref = _parse(os.path.join(REF_CFG, config.CFG_FILES[name]), {})
+    mine = _parse(config.write_cfg(str(tmp_path / "a.cfg"), name), {})
+    for k, v in mine.items():
+        if k == "minimizer_window" and not mine["use_minimizers"]:
+            continue
+        assert ref[k] == v, (name, k, ref[k], v)
+    for k in ("max_coverage_drop_rate", "chimera_window", "min_reads_in_disjointig", "max_inner_fraction",
+              "low_cutoff_warning", "add_unassembled_reads", "max_extensions_drop_rate", "max_inner_reads"):
+        assert k in mine
+
+
 def test_min_overlap_rule():
     from flye_amd import config
     assert config.min_overlap_from_reads([8000] * 10) == 5000

@@ -89,3 +89,70 @@ def test_find_all_overlaps_above_the_device_seam(built, tmp_path, name):
         want = f.read()
     assert info["find_all_overlaps"] == meta[name]["overlaps"] > 0
     assert text == want
+
+
+# ---- the reference's whole assemble stage over the seams ---------------------------------
+def _assemble_cases():
+    with open(os.path.join(GOLDEN, "assemble_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["asm_raw", "asm_hifi"])
+def test_assemble_stage_with_device_seams_writes_the_reference_draft(built, name):
+    """`flye-modules assemble` (main_assemble.cpp:123-257: index build, estimateOverlaperParameters with libc
+    rand(), Extender::assembleDisjointigs, ChimeraDetector::estimateGlobalCoverage, ConsensusGenerator) compiled
+    from the reference's files with integration/flye_seam.o in front: one thread -> draft_assembly.fasta
+    byte-identical to what the pure reference program wrote (tests/golden/make_assemble_golden.py)."""
+    from oracle import oracle as O
+    if not O.have_assemble_gpu():
+        pytest.skip("oracle/_ref/flye_assemble_gpu not built (needs /root/reference at build time)")
+    import hashlib
+    import make_assemble_golden as M
+    case = _assemble_cases()[name]
+    fasta, info = M.run_case(case, binary=O.FLYE_ASSEMBLE_GPU, threads=1)
+    assert fasta.count(b">") == case["records"] > 0
+    assert len(fasta) == case["bytes"]
+    assert hashlib.sha256(fasta).hexdigest() == case["sha256"]
+    s = info["seams"]
+    assert s["get_seq_overlaps_calls"] > 0 and s["bridge"]["device_calls"] > 0 and s["consensus_pairs"] > 0
+    print(f"{name}: wall {info['wall_s']:.1f} s, seams {s}")
+
+
+def test_assemble_stage_many_threads_completes(built):
+    """16 caller threads through the batch scheduler: the disjointigs depend on thread timing in the reference
+    itself (extender.cpp:269 takes reads under a mutex in arrival order), so only the shape is checked."""
+    from oracle import oracle as O
+    if not O.have_assemble_gpu():
+        pytest.skip("oracle/_ref/flye_assemble_gpu not built")
+    import make_assemble_golden as M
+    case = _assemble_cases()["asm_raw"]
+    fasta, info = M.run_case(case, binary=O.FLYE_ASSEMBLE_GPU, threads=16)
+    assert fasta.count(b">") >= 1 and 0.8 * case["bytes"] < len(fasta) < 1.3 * case["bytes"]
+    s = info["seams"]
+    assert s["bridge"]["requests"] >= s["bridge"]["device_calls"] > 0
+
+
+def test_consensus_alignments_as_one_device_batch(built):
+    """ConsensusGenerator::generateConsensuses through the seam's generateAlignments (every pair of every
+    disjointig in ONE fg_align_cigar_ksw batch) and, for single callers, the alignment dispatcher: the
+    consensus sequences equal the reference's (tests/golden/consensus_pairs.json) and the stage runs at >= 10x
+    the reference's one-thread rate."""
+    from oracle import oracle as O
+    if not _have():
+        pytest.skip("oracle/_ref/ref_dumper_gpu not built")
+    import hashlib
+    from helpers import edit_pair
+    with open(os.path.join(GOLDEN, "consensus_pairs.json")) as f:
+        gold = json.load(f)
+    pairs = [edit_pair(s) for s in gold["specs"]]
+    text, info = O.ref_consensus(pairs, threads=16, binary=O.REF_DUMPER_GPU)
+    assert hashlib.sha256(text.encode()).hexdigest() == gold["sha256"]
+    rate = gold["pairs"] / info["consensus_s"]
+    ref_s = gold["reference_one_thread_s"]
+    if O.have_ref():        # the compiled reference on THIS host, one thread, same pairs
+        ref_text, ref_info = O.ref_consensus(pairs, threads=1)
+        assert ref_text == text
+        ref_s = ref_info["consensus_s"]
+    ref_rate = gold["pairs"] / ref_s
+    print(f"consensus: {gold['pairs']} pairs in {info['consensus_s'] * 1e3:.0f} ms = {rate:.0f}/s; reference, one thread: {ref_rate:.0f}/s")
+    assert rate >= 10 * ref_rate
