@@ -290,6 +290,67 @@ int fg_index_finish(fg_ctx* c, const uint64_t* total_sums, struct fg_index_stats
 	});
 }
 
+int fg_index_kmer_hist(fg_ctx* c, uint64_t* hist)
+{
+	if (!c || !hist) return FG_ERR_ARG;
+	return guarded(c, [&]() { HIP_CHECK(hipSetDevice(c->device)); fgIndexKmerHist(c, hist); });
+}
+
+int fg_index_count_slice(fg_ctx* c, int32_t min_freq, float select_rate, int32_t tandem_freq, float repeat_rate,
+						 float sample_rate_init, uint32_t bin_lo, uint32_t bin_hi, uint64_t* distinct, uint32_t* n_batches)
+{
+	if (!c) return FG_ERR_ARG;
+	if (!(select_rate >= 0.0f && select_rate < 1.0f)) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgIndexCountSlice(c, min_freq, select_rate, tandem_freq, repeat_rate, sample_rate_init, bin_lo, bin_hi, distinct, n_batches);
+	});
+}
+
+int fg_index_batch_freq(fg_ctx* c, uint32_t batch, uint32_t** d_freq, uint64_t* n)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]() { HIP_CHECK(hipSetDevice(c->device)); fgIndexBatchFreq(c, batch, d_freq, n); });
+}
+
+int fg_index_batch_select(fg_ctx* c, uint32_t batch)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]() { HIP_CHECK(hipSetDevice(c->device)); fgIndexBatchSelect(c, batch); });
+}
+
+int fg_index_selection_done(fg_ctx* c, uint64_t* hist)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]() { HIP_CHECK(hipSetDevice(c->device)); fgIndexSelectionDone(c, hist); });
+}
+
+int fg_index_gather_begin(fg_ctx* c, uint64_t n_keys, uint64_t n_entries, uint64_t n_repetitive, uint64_t** full,
+						  uint64_t** piece, uint64_t* piece_sizes)
+{
+	if (!c || !full || !piece || !piece_sizes) return FG_ERR_ARG;
+	return guarded(c, [&]()
+	{
+		HIP_CHECK(hipSetDevice(c->device));
+		fgIndexGatherBegin(c, n_keys, n_entries, n_repetitive, (u64**)full, (u64**)piece, (u64*)piece_sizes);
+	});
+}
+
+int fg_index_gather_end(fg_ctx* c, float sample_rate)
+{
+	if (!c) return FG_ERR_ARG;
+	return guarded(c, [&]() { HIP_CHECK(hipSetDevice(c->device)); fgIndexGatherEnd(c, sample_rate); });
+}
+
+int fg_memory_stats(uint64_t* bytes_now, uint64_t* bytes_peak, int reset_peak)
+{
+	if (bytes_now) *bytes_now = g_fgDevBytes.load();
+	if (bytes_peak) *bytes_peak = g_fgDevPeak.load();
+	if (reset_peak) g_fgDevPeak.store(g_fgDevBytes.load());
+	return FG_OK;
+}
+
 int fg_import_index(fg_ctx* c, uint64_t n_keys, const uint64_t* keys, const uint64_t* key_off, uint64_t n_entries,
 					const uint64_t* entries, uint64_t n_repetitive, const uint64_t* repetitive_keys, float sample_rate,
 					int on_device)
@@ -326,6 +387,8 @@ int fg_clear_index(fg_ctx* c)
 		HIP_CHECK(hipSetDevice(c->device));
 		c->indexBuilt = false;
 		c->indexBuild.reset();
+		c->gathering = false;
+		c->gKeys.release(); c->gKeyOff.release(); c->gEntries.release(); c->gRepKeys.release();
 		c->dKeys.release(); c->dKeyOff.release(); c->dEntries.release(); c->dRepKeys.release();
 		c->dTable.release(); c->dIndexedBits.release();
 		c->nKeys = c->nEntries = c->nRep = c->tableSlots = 0;

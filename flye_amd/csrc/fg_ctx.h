@@ -16,6 +16,8 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <atomic>
+#include <algorithm>
 
 #include "../../include/flye_gpu.h"
 
@@ -53,6 +55,16 @@ struct FgError { int code; std::string msg; };
 	" (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"}; } } while (0)
 
 // --- device buffer -----------------------------------------------------------
+// device bytes this library holds right now / at most since the last reset, over all contexts of the process
+// (fg_memory_stats): every device allocation of the library goes through DevBuf
+inline std::atomic<unsigned long long> g_fgDevBytes{0}, g_fgDevPeak{0};
+inline void fgDevAccount(long long delta)
+{
+	const unsigned long long now = g_fgDevBytes.fetch_add((unsigned long long)delta) + (unsigned long long)delta;
+	unsigned long long pk = g_fgDevPeak.load();
+	while (delta > 0 && now > pk && !g_fgDevPeak.compare_exchange_weak(pk, now)) {}
+}
+
 template <class T>
 struct DevBuf {
 	T* p = nullptr;
@@ -61,7 +73,8 @@ struct DevBuf {
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
-	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+	void release() { if (p) { (void)hipFree(p); fgDevAccount(-(long long)(n * sizeof(T))); p = nullptr; n = 0; } }
+	void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
 	void alloc(size_t count)
 	{
 		release();
@@ -70,6 +83,7 @@ struct DevBuf {
 		if (e != hipSuccess)
 			throw FgError{FG_ERR_NOMEM, "hipMalloc of " + std::to_string(count * sizeof(T)) + " bytes: " + hipGetErrorString(e)};
 		n = count;
+		fgDevAccount((long long)(n * sizeof(T)));
 	}
 	// grow-only (keeps capacity between batches)
 	void reserve(size_t count) { if (count > n) alloc(count + count / 8); }
@@ -303,6 +317,11 @@ struct fg_ctx {
 	DevBuf<u32> dIndexedBits;	// one bit per forward k-mer position: contributes an entry
 
 	std::shared_ptr<void> indexBuild;	// state between the steps of an index build (fg_index.hip)
+	// between fg_index_gather_begin and _end: this context's own piece of a sharded build, set aside while the
+	// arrays above are the full-size ones the ranks' pieces are gathered into
+	bool gathering = false;
+	DevBuf<u64> gKeys, gKeyOff, gEntries, gRepKeys;
+	u64 gNKeys = 0, gNEntries = 0, gNRep = 0;
 
 	// overlap-stage scratch (grow-only)
 	DevBuf<u32> dQuery;			// query record indices
@@ -577,10 +596,20 @@ void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeat
 // the same in steps (sharded builds): begin -> ranges of key bins -> finish; fg_index.hip
 void fgIndexBeginSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
 					   float sampleRateInit, u64* histOut);
+// the solid selection in steps (bounded memory, counters of a key range only): count -> per batch of reads
+// {frequencies -> [sum over ranks] -> select} -> done
+void fgIndexKmerHist(fg_ctx* c, u64* histOut);
+void fgIndexCountSlice(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate, float sampleRateInit,
+					   u32 binLo, u32 binHi, u64* distinctOut, u32* nBatchesOut);
+void fgIndexBatchFreq(fg_ctx* c, u32 batch, u32** dFreq, u64* nPos);
+void fgIndexBatchSelect(fg_ctx* c, u32 batch);
+void fgIndexSelectionDone(fg_ctx* c, u64* histOut);
+void fgIndexGatherBegin(fg_ctx* c, u64 nKeys, u64 nEntries, u64 nRep, u64** full, u64** piece, u64* pieceSizes);
+void fgIndexGatherEnd(fg_ctx* c, float sampleRate);
 void fgIndexBeginMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, u64* histOut);
 void fgIndexBuildRange(fg_ctx* c, u32 binLo, u32 binHi, unsigned long long* sumsOut);
 void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stats* st);
-void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags);
+void fgIndexLookupStructures(fg_ctx* c, bool bitsHoldSelection);
 void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64 nEnt, const u64* entries, u64 nRep,
 				   const u64* repKeys, float sampleRate, int onDevice);
 // keyMode: 0 = 32-bit keys, 1 = packed 64-bit records (PK), 2 = 64-bit keys + values

@@ -11,17 +11,20 @@
 //   yieldMinimizers                     src/sequence/kmer.h:206-262
 //
 // Design (MI355X-first, not the reference's cuckoo-map-of-vectors):
-//   * counting: one u32 counter per possible k-mer, direct addressed (4^k * 4 B =
-//     68.7 GB at k = 17, sized for 288 GB HBM), one global atomic per k-mer, no CAS
-//     loop, no overflow map, exact; freed after the build like _kmerCounter.clear();
-//   * selection threshold: one workgroup per read, LDS histogram radix-select;
-//   * index: accepted (k-mer, position) pairs are emitted unordered, ordered by two
-//     stable LSD radix sorts (rocPRIM device primitive) and cut into a CSR by a
-//     head-flag scan; lookups go through a linear-probing table of 16-byte slots
-//     {key, offset<<24|count} at load <= 0.5, one dwordx4 load per probe.
+//   * counting: one u32 counter per possible k-mer of a key RANGE, direct addressed (the whole key space:
+//     4^k * 4 B = 68.7 GB at k = 17, sized for 288 GB HBM; one rank of eight: an eighth of it), in chunks of
+//     8 GiB (one allocation of 64 GiB takes seconds, eight of 8 GiB do not), one global atomic per k-mer, no
+//     CAS loop, no overflow map, exact; freed after the build like _kmerCounter.clear();
+//   * selection in BATCHES of reads: frequencies, per-read thresholds (one workgroup per read, LDS histogram
+//     radix-select), tandem filter, minimizer deque run on a bounded batch scratch; what stays is ONE BIT per
+//     k-mer position of the whole read set ("this position contributes an entry");
+//   * index: the accepted (k-mer, position) pairs of a key range are emitted in ascending position order
+//     (deterministic offsets, no cursor atomics), ordered by ONE stable LSD radix sort on the k-mer
+//     (fg_devprim.h, hand-written onesweep) and cut into a CSR by a head-flag scan; lookups go through a
+//     probing table of 8-byte slots in 64-byte groups, one line per probe.
+// Every kernel and device primitive here is hand-written; no library primitive is used.
 #include "fg_ctx.h"
-
-#include <rocprim/rocprim.hpp>
+#include "fg_devprim.h"
 
 #define WG 256
 
@@ -41,9 +44,68 @@ __device__ __forceinline__ T block_sum(T v, T* sh /* >= WG/64 */)
 	return t;	// valid on thread 0
 }
 
-// vertex_index.cpp:520-558: one increment per canonical k-mer of every forward read
+// The exact counters of the canonical k-mers in [keyLo, keyHi), in one of two forms:
+//   direct  one u32 per possible k-mer of the range; chunk c holds keys keyLo + [c << CB, (c + 1) << CB)
+//           (a read set that fills a good part of the 4^k key space: 10 Gbp of reads at k = 17);
+//   hashed  when the reads hold far fewer k-mers than the range has keys (E. coli 50x: 215 M positions against
+//           17 G keys): an open-addressing table of 8-byte slots (key << 30 | count), sized by the k-mer positions
+//           that fall into the range -- 4 GB instead of 69, no multi-second allocation, counters that stay in
+//           reach of the TLB.  Only chosen below 2^30 k-mer positions, so a count cannot reach the key bits; the
+//           all-ones slot (key T^17, never canonical) marks an empty one.
+#define FG_COUNT_CHUNK_BITS 31		// 2^31 u32 counters = 8 GiB per allocation
+#define FG_COUNT_MAX_CHUNKS 8		// k = 17: 4^17 / 2^31
+#define FG_COUNT_HBITS 30
+struct CountView {
+	u32* chunk[FG_COUNT_MAX_CHUNKS];
+	unsigned long long* table;		// hashed form (else null)
+	u64 mask;						// slots - 1
+	u64 keyLo, keyHi;
+};
+__device__ __forceinline__ bool cv_has(const CountView& cv, u64 key) { return key >= cv.keyLo && key < cv.keyHi; }
+// one more occurrence of `key`; true when it is the first
+__device__ __forceinline__ bool cv_add(const CountView& cv, u64 key)
+{
+	if (!cv.table)
+	{
+		const u64 o = key - cv.keyLo;
+		return atomicAdd(cv.chunk[o >> FG_COUNT_CHUNK_BITS] + (o & ((1ULL << FG_COUNT_CHUNK_BITS) - 1)), 1u) == 0u;
+	}
+	u64 h = fg_mix(key) & cv.mask;
+	while (true)
+	{
+		// a slot only ever goes from empty to ONE key: a stale read of it errs towards "empty" and the CAS decides
+		unsigned long long cur = cv.table[h];
+		if (cur == FG_EMPTY_KEY)
+		{
+			cur = atomicCAS(&cv.table[h], (unsigned long long)FG_EMPTY_KEY, (unsigned long long)((key << FG_COUNT_HBITS) | 1ULL));
+			if (cur == FG_EMPTY_KEY) return true;
+		}
+		if ((cur >> FG_COUNT_HBITS) == key) { atomicAdd(&cv.table[h], 1ULL); return false; }
+		h = (h + 1) & cv.mask;
+	}
+}
+// KmerCounter::getFreq of a key of the range (after the counting kernel)
+__device__ __forceinline__ u32 cv_get(const CountView& cv, u64 key)
+{
+	if (!cv.table)
+	{
+		const u64 o = key - cv.keyLo;
+		return cv.chunk[o >> FG_COUNT_CHUNK_BITS][o & ((1ULL << FG_COUNT_CHUNK_BITS) - 1)];
+	}
+	u64 h = fg_mix(key) & cv.mask;
+	while (true)
+	{
+		const unsigned long long cur = cv.table[h];
+		if (cur == FG_EMPTY_KEY) return 0u;
+		if ((cur >> FG_COUNT_HBITS) == key) return (u32)(cur & ((1ULL << FG_COUNT_HBITS) - 1));
+		h = (h + 1) & cv.mask;
+	}
+}
+
+// vertex_index.cpp:520-558: one increment per canonical k-mer of every forward read -- here: of those whose
+// canonical form lies in the counted key range (everything on one GPU, a rank's share on several)
 __global__ void k_count(const u64* __restrict__ words, const u64* __restrict__ wordOff,
-						const i32* __restrict__ len, int k, u32* __restrict__ counts,
+						const i32* __restrict__ len, int k, CountView cv,
 						unsigned long long* __restrict__ distinct)
 {
 	__shared__ u32 sh[WG / 64];
@@ -56,42 +118,45 @@ __global__ void k_count(const u64* __restrict__ words, const u64* __restrict__ w
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
 		const u64 cn = fw < rv ? fw : rv;
-		local += (atomicAdd(&counts[cn], 1u) == 0u);
+		if (cv_has(cv, cn)) local += cv_add(cv, cn) ? 1u : 0u;
 	}
 	u32 t = block_sum(local, sh);
 	if (threadIdx.x == 0 && t) atomicAdd(distinct, (unsigned long long)t);
 }
 
-// KmerCounter::getFreq for every k-mer position (vertex_index.cpp:326-333)
-__global__ void k_freq(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+// KmerCounter::getFreq for every k-mer position of the reads r0 .. r0 + gridDim.x - 1 (vertex_index.cpp:326-333);
+// positions whose k-mer lies outside the counted range get 0 (their count is another rank's: the ranks' arrays
+// add up to the complete one).  freq is the batch's array: position p of read r at kmerOff[r] - kmerOff[r0] + p
+__global__ void k_freq(u32 r0, const u64* __restrict__ words, const u64* __restrict__ wordOff,
 					   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-					   const u32* __restrict__ counts, u32* __restrict__ freq)
+					   CountView cv, u32* __restrict__ freq)
 {
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	const u64* w = words + wordOff[r];
-	u32* f = freq + kmerOff[r];
+	u32* f = freq + (kmerOff[r] - kmerOff[r0]);
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
-		f[p] = counts[fw < rv ? fw : rv];
+		const u64 cn = fw < rv ? fw : rv;
+		f[p] = cv_has(cv, cn) ? cv_get(cv, cn) : 0u;
 	}
 }
 
 // vertex_index.cpp:336-344: threshold = frequency at rank (size_t)(selectRate * n)
 // of the descending order; all k-mers with freq >= threshold are kept.
 #define HBINS 2048
-__global__ void k_threshold(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+__global__ void k_threshold(u32 r0, const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 							const u32* __restrict__ freq, float selectRate, u32* __restrict__ thr)
 {
 	__shared__ u32 hist[HBINS];
 	__shared__ u32 shThr;
 	__shared__ u32 shCnt[WG / 64];
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
-	if (nk <= 0) { if (threadIdx.x == 0) thr[r] = 0; return; }
-	const u32* f = freq + kmerOff[r];
+	if (nk <= 0) { if (threadIdx.x == 0) thr[blockIdx.x] = 0; return; }
+	const u32* f = freq + (kmerOff[r] - kmerOff[r0]);
 	for (int i = threadIdx.x; i < HBINS; i += WG) hist[i] = 0;
 	__syncthreads();
 	for (i32 p = threadIdx.x; p < nk; p += WG)
@@ -110,7 +175,7 @@ __global__ void k_threshold(const i32* __restrict__ len, const u64* __restrict__
 		shThr = v;
 	}
 	__syncthreads();
-	if (shThr < HBINS - 1) { if (threadIdx.x == 0) thr[r] = shThr; return; }
+	if (shThr < HBINS - 1) { if (threadIdx.x == 0) thr[blockIdx.x] = shThr; return; }
 	// rare: the threshold lies in the overflow bin -> bisect on the exact values
 	u32 lo = HBINS - 1, hi = 0xFFFFFFFFu;	// invariant: #(f >= lo) > maxKmers
 	while (lo < hi)
@@ -124,21 +189,22 @@ __global__ void k_threshold(const i32* __restrict__ len, const u64* __restrict__
 		if ((u64)shThr > maxKmers) lo = mid; else hi = mid - 1;
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) thr[r] = lo;
+	if (threadIdx.x == 0) thr[blockIdx.x] = lo;
 }
 
-// flags: bit0 selected (freq >= per-read threshold), bit1 tandem candidate
-__global__ void k_mark(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+// flags (one byte per position of the batch): bit0 selected (freq >= per-read threshold), bit1 tandem candidate
+__global__ void k_mark(u32 r0, const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 					   const u32* __restrict__ freq, const u32* __restrict__ thr, i32 tandemFreq,
 					   uint8_t* __restrict__ flags, unsigned long long* __restrict__ nCand)
 {
 	__shared__ u32 sh[WG / 64];
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	if (nk <= 0) return;
-	const u32* f = freq + kmerOff[r];
-	uint8_t* fl = flags + kmerOff[r];
-	const u32 t = thr[r];
+	const u64 off = kmerOff[r] - kmerOff[r0];
+	const u32* f = freq + off;
+	uint8_t* fl = flags + off;
+	const u32 t = thr[blockIdx.x];
 	u32 c = 0;
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
@@ -154,21 +220,21 @@ __global__ void k_mark(const i32* __restrict__ len, const u64* __restrict__ kmer
 // vertex_index.cpp:346-355: k-mers occurring > tandemFreq times inside ONE read are
 // dropped.  Only candidates (global freq > tandemFreq) can qualify; they are
 // counted exactly in a (read, k-mer) keyed table.
-__global__ void k_tandem_insert(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+__global__ void k_tandem_insert(u32 r0, const u64* __restrict__ words, const u64* __restrict__ wordOff,
 								const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 								const uint8_t* __restrict__ flags, u64* __restrict__ tkeys,
 								u32* __restrict__ tcnt, u64 tmask)
 {
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	const u64* w = words + wordOff[r];
-	const uint8_t* fl = flags + kmerOff[r];
+	const uint8_t* fl = flags + (kmerOff[r] - kmerOff[r0]);
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
 		if (!(fl[p] & 2)) continue;
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
-		const u64 key = ((u64)r << 34) | (fw < rv ? fw : rv);
+		const u64 key = ((u64)blockIdx.x << 34) | (fw < rv ? fw : rv);
 		u64 h = fg_mix(key) & tmask;
 		while (true)
 		{
@@ -180,21 +246,21 @@ __global__ void k_tandem_insert(const u64* __restrict__ words, const u64* __rest
 	}
 }
 
-__global__ void k_tandem_apply(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+__global__ void k_tandem_apply(u32 r0, const u64* __restrict__ words, const u64* __restrict__ wordOff,
 							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 							   uint8_t* __restrict__ flags, const u64* __restrict__ tkeys,
 							   const u32* __restrict__ tcnt, u64 tmask, i32 tandemFreq)
 {
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	const u64* w = words + wordOff[r];
-	uint8_t* fl = flags + kmerOff[r];
+	uint8_t* fl = flags + (kmerOff[r] - kmerOff[r0]);
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
 		if (!(fl[p] & 2)) continue;
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
-		const u64 key = ((u64)r << 34) | (fw < rv ? fw : rv);
+		const u64 key = ((u64)blockIdx.x << 34) | (fw < rv ? fw : rv);
 		u64 h = fg_mix(key) & tmask;
 		while (tkeys[h] != key) h = (h + 1) & tmask;
 		if (tcnt[h] > (u32)tandemFreq) fl[p] = 0;
@@ -202,16 +268,17 @@ __global__ void k_tandem_apply(const u64* __restrict__ words, const u64* __restr
 }
 
 // bit0 := accepted for the index (selected, not tandem, freq >= minFreq)
-__global__ void k_accept(const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+__global__ void k_accept(u32 r0, const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
 						 const u32* __restrict__ freq, i32 minFreq, uint8_t* __restrict__ flags,
 						 unsigned long long* __restrict__ nAcc)
 {
 	__shared__ u32 sh[WG / 64];
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	if (nk <= 0) return;
-	const u32* f = freq + kmerOff[r];
-	uint8_t* fl = flags + kmerOff[r];
+	const u64 off = kmerOff[r] - kmerOff[r0];
+	const u32* f = freq + off;
+	uint8_t* fl = flags + off;
 	u32 c = 0;
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
@@ -223,6 +290,24 @@ __global__ void k_accept(const i32* __restrict__ len, const u64* __restrict__ km
 	if (threadIdx.x == 0 && tot) atomicAdd(nAcc, (unsigned long long)tot);
 }
 
+// the batch's byte flags -> the read set's bit array: thread per 32-bit word touched by positions
+// [posBase, posBase + nPos) (a word at a batch boundary is shared with the neighbouring batch: atomicOr)
+__global__ void k_pack_bits(const uint8_t* __restrict__ flags, u64 posBase, u64 nPos, u32* __restrict__ bits)
+{
+	const u64 w = (posBase >> 5) + (u64)blockIdx.x * WG + threadIdx.x;
+	if (w > ((posBase + nPos - 1) >> 5)) return;
+	u32 v = 0;
+#pragma unroll 8
+	for (int j = 0; j < 32; ++j)
+	{
+		const u64 pos = w * 32 + j;
+		if (pos >= posBase && pos < posBase + nPos && flags[pos - posBase]) v |= 1u << j;
+	}
+	if (v) atomicOr(&bits[w], v);
+}
+
+__device__ __forceinline__ bool fg_bit(const u32* __restrict__ bits, u64 i) { return (bits[i >> 5] >> (i & 31)) & 1u; }
+
 // ---- minimizer sketch (kmer.h:206-262) ------------------------------------------
 // The sketch equals "the sequence of distinct deque fronts".  Whenever hash[p] is
 // strictly below the w previous hashes (or p == 0) the deque collapses to [p]
@@ -230,18 +315,18 @@ __global__ void k_accept(const i32* __restrict__ len, const u64* __restrict__ km
 // is an independent piece: sync points are found in parallel, then one lane runs
 // the literal deque loop over one piece.
 #define MAXW 64
-__global__ void k_minimizers(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+__global__ void k_minimizers(u32 r0, const u64* __restrict__ words, const u64* __restrict__ wordOff,
 							 const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k, int w,
-							 u64* __restrict__ hashes /* per k-mer position scratch */,
-							 uint8_t* __restrict__ flags, unsigned long long* __restrict__ nAcc)
+							 u64* __restrict__ hashes /* scratch, one per k-mer position of the batch */,
+							 uint8_t* __restrict__ flags /* of the batch */, unsigned long long* __restrict__ nAcc)
 {
 	__shared__ u32 sh[WG / 64];
-	const u32 r = blockIdx.x;
+	const u32 r = r0 + blockIdx.x;
 	const i32 nk = len[r] - k;
 	if (nk <= 0) return;
 	const u64* wd = words + wordOff[r];
-	u64* hs = hashes + kmerOff[r];
-	uint8_t* fl = flags + kmerOff[r];
+	u64* hs = hashes + (kmerOff[r] - kmerOff[r0]);
+	uint8_t* fl = flags + (kmerOff[r] - kmerOff[r0]);
 	if (w == 1)
 	{
 		u32 c = 0;
@@ -303,74 +388,113 @@ __global__ void k_minimizers(const u64* __restrict__ words, const u64* __restric
 
 // canonical-orientation entry of every accepted position (vertex_index.cpp:76-85):
 // value = (record << posBits) | position with record = 2*read (+1 if the k-mer was
-// flipped, position mirrored)
-__global__ void k_emit(const u64* __restrict__ words, const u64* __restrict__ wordOff,
-					   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-					   const uint8_t* __restrict__ flags, int posBits, u64 keyLo, u64 keyHi /* canonical k-mers in [lo, hi) */,
-					   u64* __restrict__ ecanon, u64* __restrict__ evalue, unsigned long long* __restrict__ cursor)
+// flipped, position mirrored).  The pairs of a key range leave in ASCENDING VALUE order: read by read, a read's
+// unflipped positions in ascending p (record 2r), then its flipped ones in DESCENDING p (record 2r + 1, position
+// L - p - k ascending) -- so that one stable sort by k-mer leaves every list in ascending (record, position) order
+// (vertex_index.cpp:108-114) and no sort by value is needed.  Pass 1 (k_emit_count) counts a read's pairs in the
+// range, a scan over the reads gives its first slot, pass 2 (k_emit_write) places them.
+__device__ __forceinline__ bool emit_take(const u64* __restrict__ w, const u32* __restrict__ bits, u64 base, i32 p, int k,
+										  bool all, u64 keyLo, u64 keyHi, u64& canon, bool& flip)
 {
+	if (!fg_bit(bits, base + (u64)p)) return false;
+	u64 fw, rv;
+	fg_kmer_pair(w, p, k, fw, rv);
+	flip = rv < fw;
+	canon = flip ? rv : fw;
+	return all || (canon >= keyLo && canon < keyHi);
+}
+
+__global__ void k_emit_count(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+							 const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+							 const u32* __restrict__ bits, u64 keyLo, u64 keyHi, u64* __restrict__ perRead)
+{
+	__shared__ u32 sh[WG / 64];
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const u64 base = kmerOff[r];
+	const bool all = keyLo == 0 && keyHi == ~0ULL;
+	u32 mine = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		u64 cn; bool fl;
+		mine += emit_take(w, bits, base, p, k, all, keyLo, keyHi, cn, fl) ? 1u : 0u;
+	}
+	const u32 t = block_sum(mine, sh);
+	if (threadIdx.x == 0) perRead[r] = t;
+}
+
+__global__ void k_emit_write(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+							 const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+							 const u32* __restrict__ bits, int posBits, u64 keyLo, u64 keyHi,
+							 const u64* __restrict__ readStart /* exclusive scan of perRead */,
+							 u64* __restrict__ ecanon, u64* __restrict__ evalue)
+{
+	__shared__ u32 shU[WG / 64], shF[WG / 64];
 	const u32 r = blockIdx.x;
 	const i32 L = len[r];
 	const i32 nk = L - k;
+	const u64 first = readStart[r], cnt = readStart[r + 1] - first;
+	if (cnt == 0) return;
 	const u64* w = words + wordOff[r];
-	const uint8_t* fl = flags + kmerOff[r];
+	const u64 base = kmerOff[r];
 	const bool all = keyLo == 0 && keyHi == ~0ULL;
-	auto inSlice = [&](i32 p) -> bool
-	{
-		if (all) return true;
-		u64 fw, rv;
-		fg_kmer_pair(w, p, k, fw, rv);
-		const u64 c = fw < rv ? fw : rv;
-		return c >= keyLo && c < keyHi;
-	};
-	// ONE cursor atomic per read: same-address atomics serialise at ~11 ns each, and one per
-	// wave and step (what the compiler's aggregation of a per-element atomicAdd gives) was 3.4 M of
-	// them = 39 of the build's 85 ms.  The emission order is irrelevant (radix sort follows).
-	__shared__ u32 shw[WG / 64];
-	__shared__ u64 shBase;
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-	u32 mine = 0;
-	for (i32 p = threadIdx.x; p < nk; p += WG) mine += (fl[p] && inSlice(p)) ? 1u : 0u;
-	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-	if (lane == 0) shw[wv] = mine;
-	__syncthreads();
-	if (threadIdx.x == 0)
+	const u64 below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+	// unflipped pairs of the read in the range: they come first
+	u32 mineU = 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
-		u32 tot = 0;
-		for (int i = 0; i < WG / 64; ++i) tot += shw[i];
-		shBase = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ULL;
+		u64 cn; bool fl;
+		if (emit_take(w, bits, base, p, k, all, keyLo, keyHi, cn, fl) && !fl) ++mineU;
 	}
+	for (int o = 32; o > 0; o >>= 1) mineU += __shfl_down(mineU, o);
+	if (lane == 0) shU[wv] = mineU;
 	__syncthreads();
-	u64 base = shBase;
+	u64 totU = 0;
+	for (int i = 0; i < WG / 64; ++i) totU += shU[i];
+	__syncthreads();
+	u64 doneU = 0, doneF = 0;	// pairs of each kind at positions below the current step
 	for (i32 p0 = 0; p0 < nk; p0 += WG)
 	{
 		const i32 p = p0 + (i32)threadIdx.x;
-		const bool take = p < nk && fl[p] && inSlice(p);
-		const u64 m = __ballot(take);
+		u64 cn = 0; bool fl = false;
+		const bool take = p < nk && emit_take(w, bits, base, p, k, all, keyLo, keyHi, cn, fl);
+		const u64 mU = __ballot(take && !fl), mF = __ballot(take && fl);
+		if (lane == 0) { shU[wv] = (u32)__popcll(mU); shF[wv] = (u32)__popcll(mF); }
 		__syncthreads();
-		if (lane == 0) shw[wv] = (u32)__popcll(m);
-		__syncthreads();
-		u32 before = 0, tot = 0;
-		for (int i = 0; i < WG / 64; ++i) { const u32 c = shw[i]; if (i < wv) before += c; tot += c; }
+		u32 beforeU = 0, beforeF = 0, stepU = 0, stepF = 0;
+		for (int i = 0; i < WG / 64; ++i)
+		{
+			const u32 cu = shU[i], cf = shF[i];
+			if (i < wv) { beforeU += cu; beforeF += cf; }
+			stepU += cu; stepF += cf;
+		}
 		if (take)
 		{
-			u64 fw, rv;
-			fg_kmer_pair(w, p, k, fw, rv);
-			const bool flip = rv < fw;
-			const u64 slot = base + before + (u64)__popcll(m & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane))));
-			ecanon[slot] = flip ? rv : fw;
-			evalue[slot] = ((u64)(2 * r + (flip ? 1 : 0)) << posBits) | (u64)(flip ? L - p - k : p);
+			u64 slot;
+			if (!fl) slot = first + doneU + beforeU + (u64)__popcll(mU & below);
+			else
+			{
+				// flipped pairs: the one at the highest p has the lowest mirrored position and goes first
+				const u64 rankF = doneF + beforeF + (u64)__popcll(mF & below);		// rank in ascending p
+				slot = first + totU + (cnt - totU - 1 - rankF);
+			}
+			ecanon[slot] = cn;
+			evalue[slot] = ((u64)(2 * r + (fl ? 1 : 0)) << posBits) | (u64)(fl ? L - p - k : p);
 		}
-		base += tot;
+		doneU += stepU; doneF += stepF;
+		__syncthreads();
 	}
 }
 
-// accepted positions per key bin (bin = canonical k-mer >> binShift): what the slicing of the build --
-// by memory on one GPU, by rank on several -- balances on
+// positions per key bin (bin = canonical k-mer >> binShift) -- of the accepted positions (bits != null: what the
+// slicing of the build, by memory on one GPU and by rank on several, balances on), or of ALL k-mer positions
+// (bits == null: what the ranks' counter ranges are balanced on before anything is selected)
 #define FG_INDEX_BINS 4096
 __global__ void k_bin_hist(const u64* __restrict__ words, const u64* __restrict__ wordOff,
 						   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-						   const uint8_t* __restrict__ flags, int binShift, unsigned long long* __restrict__ hist)
+						   const u32* __restrict__ bits, int binShift, unsigned long long* __restrict__ hist)
 {
 	__shared__ u32 sh[FG_INDEX_BINS];
 	for (int i = threadIdx.x; i < FG_INDEX_BINS; i += WG) sh[i] = 0;
@@ -378,9 +502,9 @@ __global__ void k_bin_hist(const u64* __restrict__ words, const u64* __restrict_
 	const u32 r = blockIdx.x;
 	const i32 nk = len[r] - k;
 	const u64* w = words + wordOff[r];
-	const uint8_t* fl = flags + kmerOff[r];
+	const u64 base = kmerOff[r];
 	for (i32 p = threadIdx.x; p < nk; p += WG)
-		if (fl[p])
+		if (!bits || fg_bit(bits, base + (u64)p))
 		{
 			u64 fw, rv;
 			fg_kmer_pair(w, p, k, fw, rv);
@@ -425,7 +549,7 @@ __global__ void k_capstats(const u64* __restrict__ kstart, u64 nKeys, i32 minCov
 // vertex_index.cpp:189-202 (repetitive keys leave the index), :70-71 (entries are
 // written only when minFreq <= freq <= repFreq), :370-373 (capacity limit)
 __global__ void k_classify(const u64* __restrict__ ukeys, const u64* __restrict__ kstart, u64 nKeys,
-						   u64 repFreq, const u32* __restrict__ counts /* null in minimizer mode */,
+						   u64 repFreq, int solid /* 0 in minimizer mode */, CountView cv,
 						   u32* __restrict__ isRep, u32* __restrict__ keep, u64* __restrict__ size,
 						   u32* __restrict__ err)
 {
@@ -434,7 +558,7 @@ __global__ void k_classify(const u64* __restrict__ ukeys, const u64* __restrict_
 	const u64 cap = kstart[j + 1] - kstart[j];
 	const bool rep = cap > repFreq;
 	bool filled = !rep;
-	if (filled && counts) filled = (u64)counts[ukeys[j]] <= repFreq;
+	if (filled && solid) filled = (u64)cv_get(cv, ukeys[j]) <= repFreq;
 	isRep[j] = rep;
 	keep[j] = !rep;
 	size[j] = filled ? cap : 0;
@@ -443,7 +567,7 @@ __global__ void k_classify(const u64* __restrict__ ukeys, const u64* __restrict_
 
 // totals of one part under the final repFreq: repetitive keys, kept keys, entries (same rules as k_classify)
 __global__ void k_classify_count(const u64* __restrict__ ukeys, const u64* __restrict__ kstart, u64 nKeys, u64 repFreq,
-								 const u32* __restrict__ counts, unsigned long long* __restrict__ out /* rep, keep, entries */)
+								 int solid, CountView cv, unsigned long long* __restrict__ out /* rep, keep, entries */)
 {
 	__shared__ u64 sh[WG / 64];
 	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
@@ -453,7 +577,7 @@ __global__ void k_classify_count(const u64* __restrict__ ukeys, const u64* __res
 		const u64 cap = kstart[j + 1] - kstart[j];
 		const bool r = cap > repFreq;
 		bool filled = !r;
-		if (filled && counts) filled = (u64)counts[ukeys[j]] <= repFreq;
+		if (filled && solid) filled = (u64)cv_get(cv, ukeys[j]) <= repFreq;
 		rep = r; keep = !r; ent = filled ? cap : 0;
 	}
 	u64 t = block_sum(rep, sh);
@@ -537,71 +661,71 @@ __global__ void k_table_insert(const u64* __restrict__ keys, const u64* __restri
 // one bit per forward k-mer position: does this position own an index entry?
 // (lets the seed collector skip the trivial self hit, overlap.cpp:188-190,
 // without searching the list)
-__global__ void k_indexed_bits(const u64* __restrict__ words, const u64* __restrict__ wordOff,
-							   const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
-							   const uint8_t* __restrict__ flags /* the build's selection, or null */,
-							   FgTable T, int wide, const u64* __restrict__ entries, u32* __restrict__ bits)
+// Form 1, after a build: the array holds the build's selection bits; a selected position owns an entry unless its
+// k-mer left the index (repetitive, or a list left empty) -- those bits are cleared in place.
+template <bool WIDE>
+__global__ void k_indexed_clear(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+								const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+								FgTable T, u32* __restrict__ bits)
+{
+	const u32 r = blockIdx.x;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const u64 base = kmerOff[r];
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		if (!fg_bit(bits, base + (u64)p)) continue;
+		u64 fw, rv;
+		fg_kmer_pair(w, p, k, fw, rv);
+		const u64 v = fg_probe<WIDE>(T, rv < fw ? rv : fw);
+		if (v == 0 || (v & FG_CNT_MASK) == FG_CNT_REPETITIVE)
+			atomicAnd(&bits[(base + p) >> 5], ~(1u << ((base + p) & 31)));
+	}
+}
+// Form 2, an imported index (no selection at hand; bits start zeroed): a position owns an entry iff its own
+// (record, position) is in the k-mer's list (ascending, vertex_index.cpp:108-114)
+template <bool WIDE>
+__global__ void k_indexed_search(const u64* __restrict__ words, const u64* __restrict__ wordOff,
+								 const i32* __restrict__ len, const u64* __restrict__ kmerOff, int k,
+								 FgTable T, const u64* __restrict__ entries, u32* __restrict__ bits)
 {
 	const u32 r = blockIdx.x;
 	const i32 L = len[r];
 	const i32 nk = L - k;
 	const u64* w = words + wordOff[r];
-	const uint8_t* fl = flags ? flags + kmerOff[r] : nullptr;
 	const u64 base = kmerOff[r];
 	for (i32 p = threadIdx.x; p < nk; p += WG)
 	{
-		if (fl && !fl[p]) continue;
 		u64 fw, rv;
 		fg_kmer_pair(w, p, k, fw, rv);
 		const bool flip = rv < fw;
-		const u64 v = wide ? fg_probe<true>(T, flip ? rv : fw) : fg_probe<false>(T, flip ? rv : fw);
+		const u64 v = fg_probe<WIDE>(T, flip ? rv : fw);
 		if (v == 0 || (v & FG_CNT_MASK) == FG_CNT_REPETITIVE) continue;
-		if (!fl)
-		{
-			// an imported index carries no selection flags: a position owns an entry iff its own
-			// (record, position) is in the k-mer's list (ascending, vertex_index.cpp:108-114)
-			const u64 own = ((u64)(2 * r + (flip ? 1u : 0u)) << 32) | (u32)(flip ? L - p - k : p);
-			const u64* e = entries + ((v >> FG_CNT_BITS) & ((1ULL << 38) - 1));
-			u32 lo = 0, hi = (u32)(v & FG_CNT_MASK);
-			while (lo < hi) { const u32 m = (lo + hi) >> 1; if (e[m] < own) lo = m + 1; else hi = m; }
-			if (lo >= (u32)(v & FG_CNT_MASK) || e[lo] != own) continue;
-		}
+		const u64 own = ((u64)(2 * r + (flip ? 1u : 0u)) << 32) | (u32)(flip ? L - p - k : p);
+		const u64* e = entries + ((v >> FG_CNT_BITS) & ((1ULL << 38) - 1));
+		u32 lo = 0, hi = (u32)(v & FG_CNT_MASK);
+		while (lo < hi) { const u32 m = (lo + hi) >> 1; if (e[m] < own) lo = m + 1; else hi = m; }
+		if (lo >= (u32)(v & FG_CNT_MASK) || e[lo] != own) continue;
 		atomicOr(&bits[(base + p) >> 5], 1u << ((base + p) & 31));
 	}
 }
 
-// ---- host helpers -----------------------------------------------------------------
-struct Prim {
-	fg_ctx* c;
-	DevBuf<char> tmp;
-	void sortPairs(u64* kin, u64* kout, u64* vin, u64* vout, u64 n, int bits)
-	{
-		if (n == 0) return;
-		size_t bytes = 0;
-		HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, c->stream));
-		tmp.reserve(bytes);
-		HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0, bits, c->stream));
-	}
-	template <class T>
-	void incScan(const T* in, T* out, u64 n)
-	{
-		if (n == 0) return;
-		size_t bytes = 0;
-		HIP_CHECK(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), c->stream));
-		tmp.reserve(bytes);
-		HIP_CHECK(rocprim::inclusive_scan(tmp.p, bytes, in, out, n, rocprim::plus<T>(), c->stream));
-	}
-	template <class T>
-	void excScan(const T* in, T* out, u64 n)
-	{
-		if (n == 0) return;
-		size_t bytes = 0;
-		HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
-		tmp.reserve(bytes);
-		HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, T(0), n, rocprim::plus<T>(), c->stream));
-	}
-};
+// an imported CSR must be well formed before anything reads lists through it: offsets start at 0, never
+// decrease, end at nEntries; keys strictly ascending
+__global__ void k_check_csr(const u64* __restrict__ keys, const u64* __restrict__ keyOff, u64 nKeys, u64 nEntries,
+							u32* __restrict__ bad)
+{
+	const u64 j = (u64)blockIdx.x * WG + threadIdx.x;
+	if (j > nKeys) return;
+	bool ok = true;
+	if (j == 0) ok = keyOff[0] == 0;
+	if (j == nKeys) ok = ok && keyOff[nKeys] == nEntries;
+	if (j < nKeys) ok = ok && keyOff[j] <= keyOff[j + 1] && keyOff[j + 1] <= nEntries;
+	if (j + 1 < nKeys) ok = ok && keys[j] < keys[j + 1];
+	if (!ok) atomicExch(bad, 1u);
+}
 
+// ---- host helpers -----------------------------------------------------------------
 template <class T>
 T fetch(fg_ctx* c, const T* dptr)
 {
@@ -615,20 +739,21 @@ int bitsFor(u64 v) { int b = 1; while ((1ULL << b) <= v && b < 63) ++b; return b
 unsigned gridFor(u64 n) { return (unsigned)((n + WG - 1) / WG); }
 
 
-// ---- the build in three steps ------------------------------------------------------------------
-//   begin        k-mer selection over ALL reads (solid: exact counts + per-read frequency threshold +
-//                tandem filter, vertex_index.cpp:19-125; minimizers: kmer.h:206-262) -> one flag per
-//                k-mer position, and the number of accepted positions per key bin
-//   build range  for the keys of bins [lo, hi): emit (canonical k-mer, position) pairs, two stable
-//                LSD radix sorts (position, then k-mer), run-length encode -> one PART (unique keys,
-//                list starts, sorted positions) + its share of filterFrequentKmers' sums
-//                (vertex_index.cpp:175-184).  Ranges wider than the memory budget are cut.
+// ---- the build in steps ------------------------------------------------------------------------
+//   selection    over ALL reads (solid: exact counts + per-read frequency threshold + tandem filter,
+//                vertex_index.cpp:19-125; minimizers: kmer.h:206-262), in batches of reads on a bounded scratch
+//                -> one BIT per k-mer position, and the number of accepted positions per key bin.
+//                Solid mode in steps of its own (several GPUs): count slice -> per batch
+//                {frequencies of the slice's k-mers -> summed over the ranks -> select} -> done;
+//   build range  for the keys of bins [lo, hi): emit (canonical k-mer, position) pairs in position order, one
+//                stable LSD radix sort by k-mer, run-length encode -> one PART (unique keys, list starts, sorted
+//                positions) + its share of filterFrequentKmers' sums (vertex_index.cpp:175-184).  Ranges wider
+//                than the memory budget are cut;
 //   finish       with the sums over ALL keys: repetitive frequency, classification, CSR arrays in key
 //                order, probe table, indexed bits.
-// One GPU runs begin, the whole key space, finish.  Several GPUs each run begin (replicated: the
-// selection needs every read), the range their rank owns (flye_amd/dist.py balances the ranges on
-// the bin histogram), exchange the two sums, finish their piece, all-gather the pieces and import the
-// concatenation (fgImportIndex) -- SURVEY.md §8(e).
+// One GPU runs the selection, the whole key space, finish.  Several GPUs each run the selection (counters of
+// their key range only), the range their rank owns, exchange the two sums, finish their piece and gather the
+// pieces into full-size arrays (fg_index_gather_begin / _end) -- SURVEY.md §8(e).
 struct IndexPart {
 	DevBuf<u64> ukeys, kstart, evalue;
 	DevBuf<u32> inc;
@@ -637,8 +762,22 @@ struct IndexPart {
 
 struct IndexBuild {
 	bool solid = false;
-	DevBuf<u32> counts;			// solid mode: exact count of every possible k-mer
-	DevBuf<uint8_t> flags;		// 1 = this k-mer position contributes an entry
+	// solid mode: exact counters of the canonical k-mers of the key bins [cntBinLo, cntBinHi)
+	DevBuf<u32> countChunk[FG_COUNT_MAX_CHUNKS];
+	DevBuf<unsigned long long> countTable;
+	CountView cv{};
+	i32 minFreq = 0, tandemFreq = 0;
+	float selectRate = 0;
+	// selection: one bit per k-mer position of the read set; scratch of the batch in work
+	DevBuf<u32> bits;
+	std::vector<u32> batchStart;	// first read of each batch; back() = number of reads
+	u64 batchCap = 0;				// k-mer positions of the largest batch
+	u32 batchReads = 0;				// reads of the largest batch
+	DevBuf<u32> freq, thr;
+	DevBuf<uint8_t> flags;
+	DevBuf<u64> hashes;
+	DevBuf<unsigned long long> scal;	// [0] distinct, [1] tandem candidates (per batch), [2] accepted
+	bool selectionDone = false;
 	int posBits = 0, binShift = 0;
 	i32 minCoverage = 0;
 	float repeatRate = 0, sampleRateInit = 1.0f;
@@ -646,6 +785,7 @@ struct IndexBuild {
 	std::vector<u64> hist;		// accepted positions per bin
 	std::vector<std::unique_ptr<IndexPart>> parts;	// ascending key ranges
 	unsigned long long sums[2] = {0, 0};
+	DevBuf<char> scratch;		// radix sort status words / scan tile sums
 	double seconds = 0;
 };
 
@@ -675,65 +815,129 @@ IndexBuild* buildState(fg_ctx* c)
 void clearIndex(fg_ctx* c)
 {
 	c->indexBuilt = false;
+	c->gathering = false;
+	c->gKeys.release(); c->gKeyOff.release(); c->gEntries.release(); c->gRepKeys.release();
 	c->dKeys.release(); c->dKeyOff.release(); c->dEntries.release(); c->dRepKeys.release();
 	c->dTable.release(); c->dIndexedBits.release();
 	c->nKeys = c->nEntries = c->nRep = c->tableSlots = 0;
 }
 
-void binHistogram(fg_ctx* c, IndexBuild* B, u64* histOut)
+int binShiftFor(int k) { return std::max(0, 2 * k - 12); }
+
+// per key bin: accepted positions (bits) or all k-mer positions (bits == null)
+void binHistogram(fg_ctx* c, const u32* bits, int binShift, std::vector<u64>& hist)
 {
 	hipStream_t s = c->stream;
-	const int k = c->k;
-	B->binShift = std::max(0, 2 * k - 12);
 	DevBuf<unsigned long long> dh;
 	dh.alloc(FG_INDEX_BINS);
 	HIP_CHECK(hipMemsetAsync(dh.p, 0, FG_INDEX_BINS * 8, s));
 	if (c->nReads)
 	{
 		ScopedK t(c->timer, "k_bin_hist");
-		hipLaunchKernelGGL(k_bin_hist, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-						   B->flags.p, B->binShift, dh.p);
+		hipLaunchKernelGGL(k_bin_hist, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
+						   bits, binShift, dh.p);
 	}
-	B->hist.assign(FG_INDEX_BINS, 0);
-	HIP_CHECK(hipMemcpyAsync(B->hist.data(), dh.p, FG_INDEX_BINS * 8, hipMemcpyDeviceToHost, s));
+	hist.assign(FG_INDEX_BINS, 0);
+	HIP_CHECK(hipMemcpyAsync(hist.data(), dh.p, FG_INDEX_BINS * 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	if (histOut) memcpy(histOut, B->hist.data(), FG_INDEX_BINS * 8);
+}
+
+// what every selection starts with: a cleared index, the bit array, the batches
+std::shared_ptr<IndexBuild> beginCommon(fg_ctx* c)
+{
+	hipStream_t s = c->stream;
+	clearIndex(c);
+	c->timer.reset();
+	c->indexBuild.reset();
+	std::shared_ptr<IndexBuild> B(new IndexBuild);
+	B->posBits = bitsFor((u64)c->maxLen);
+	B->binShift = binShiftFor(c->k);
+	B->bits.alloc((c->totalKmers + 31) / 32 + 1);
+	HIP_CHECK(hipMemsetAsync(B->bits.p, 0, B->bits.bytes(), s));
+	B->scal.alloc(4);
+	HIP_CHECK(hipMemsetAsync(B->scal.p, 0, 32, s));
+	// batches of whole reads, at most `budget` k-mer positions each (a longer read is a batch of its own)
+	const u64 budget = getenv("FG_INDEX_BATCH_KMERS") ? std::max<u64>(1, strtoull(getenv("FG_INDEX_BATCH_KMERS"), nullptr, 10))
+													   : (256ULL << 20);
+	B->batchStart.assign(1, 0);
+	u64 acc = 0;
+	u32 first = 0;
+	for (u32 r = 0; r < c->nReads; ++r)
+	{
+		const u64 nk = c->hKmerOff[r + 1] - c->hKmerOff[r];
+		if (r > first && acc + nk > budget)
+		{
+			B->batchCap = std::max(B->batchCap, acc); B->batchReads = std::max(B->batchReads, r - first);
+			B->batchStart.push_back(r); first = r; acc = 0;
+		}
+		acc += nk;
+	}
+	B->batchCap = std::max(B->batchCap, acc); B->batchReads = std::max(B->batchReads, c->nReads - first);
+	if (c->nReads) B->batchStart.push_back(c->nReads);
+	return B;
+}
+
+void packBatch(fg_ctx* c, IndexBuild* B, u32 r0, u32 r1)
+{
+	const u64 posBase = c->hKmerOff[r0], nPos = c->hKmerOff[r1] - posBase;
+	if (!nPos) return;
+	const u64 words = ((posBase + nPos - 1) >> 5) - (posBase >> 5) + 1;
+	ScopedK t(c->timer, "k_pack_bits");
+	hipLaunchKernelGGL(k_pack_bits, gridFor(words), WG, 0, c->stream, B->flags.p, posBase, nPos, B->bits.p);
 }
 
 // one slice of keys -> one part
-void buildPart(fg_ctx* c, IndexBuild* B, Prim& prim, u32 binLo, u32 binHi, u64 E)
+void buildPart(fg_ctx* c, IndexBuild* B, u32 binLo, u32 binHi, u64 E)
 {
 	if (E == 0) return;
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	const u32 n = c->nReads;
-	const u64 keyLo = (u64)binLo << B->binShift;
-	const u64 keyHi = binHi >= FG_INDEX_BINS ? ~0ULL : ((u64)binHi << B->binShift);
+	const bool all = binLo == 0 && binHi >= FG_INDEX_BINS;
+	const u64 keyLo = all ? 0ULL : ((u64)binLo << B->binShift);
+	const u64 keyHi = (all || binHi >= FG_INDEX_BINS) ? ~0ULL : ((u64)binHi << B->binShift);
+	if (E > fgprim::RS_MAX_N) throw FgError{FG_ERR_ARG, "index slice above 2^30 entries (FG_INDEX_SLICE_ENTRIES)"};
 	std::unique_ptr<IndexPart> part(new IndexPart);
-	DevBuf<u64> ecanon, ecanon2, evalue2;
-	DevBuf<unsigned long long> cursor;
-	ecanon.alloc(E); part->evalue.alloc(E); cursor.alloc(1);
-	HIP_CHECK(hipMemsetAsync(cursor.p, 0, 8, s));
+	// where each read's pairs go: count, scan over the reads
+	DevBuf<u64> readStart;
+	readStart.alloc((u64)n + 1);
+	HIP_CHECK(hipMemsetAsync(readStart.p + n, 0, 8, s));
 	{
 		ScopedK t(c->timer, "k_emit");
-		hipLaunchKernelGGL(k_emit, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->flags.p,
-						   B->posBits, (binLo == 0 && binHi >= FG_INDEX_BINS) ? 0ULL : keyLo,
-						   (binLo == 0 && binHi >= FG_INDEX_BINS) ? ~0ULL : keyHi, ecanon.p, part->evalue.p, cursor.p);
+		hipLaunchKernelGGL(k_emit_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->bits.p,
+						   keyLo, keyHi, readStart.p);
 	}
-	if (fetch(c, cursor.p) != E) throw FgError{FG_ERR_HIP, "internal: slice emission does not match the bin histogram"};
-	ecanon2.alloc(E); evalue2.alloc(E);
-	const int valBits = B->posBits + bitsFor(2ULL * n);
+	B->scratch.reserve(std::max<size_t>(fgprim::radixSortScratchBytes(E),
+										fgprim::scanScratchElems(std::max<u64>(E, (u64)n + 1)) * 8));
 	{
-		ScopedK t(c->timer, "radix_sort_pairs(rocprim)");
-		prim.sortPairs(part->evalue.p, evalue2.p, ecanon.p, ecanon2.p, E, valBits);
-		prim.sortPairs(ecanon2.p, ecanon.p, evalue2.p, part->evalue.p, E, 2 * k);
+		ScopedK t(c->timer, "scan");
+		fgprim::scan<u64>(s, readStart.p, readStart.p, (u64)n + 1, false, (u64*)B->scratch.p);
+	}
+	if (fetch(c, readStart.p + n) != E) throw FgError{FG_ERR_HIP, "internal: slice emission does not match the bin histogram"};
+	DevBuf<u64> ecanon, ecanon2, evalue2;
+	ecanon.alloc(E); part->evalue.alloc(E);
+	{
+		ScopedK t(c->timer, "k_emit");
+		hipLaunchKernelGGL(k_emit_write, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->bits.p,
+						   B->posBits, keyLo, keyHi, readStart.p, ecanon.p, part->evalue.p);
+	}
+	readStart.release();
+	ecanon2.alloc(E); evalue2.alloc(E);
+	{
+		// the pairs lie in ascending (record, position) order: ONE stable sort by k-mer
+		ScopedK t(c->timer, "radix_sort_pairs");
+		if (fgprim::radixSortPairs(s, ecanon.p, part->evalue.p, ecanon2.p, evalue2.p, E, 0, 2 * k, B->scratch.p))
+		{
+			ecanon.swap(ecanon2);
+			part->evalue.swap(evalue2);
+		}
 	}
 	ecanon2.release(); evalue2.release();
 	// run-length encode the sorted k-mers
 	DevBuf<u32> flag;
 	flag.alloc(E); part->inc.alloc(E);
 	{ ScopedK t(c->timer, "k_heads"); hipLaunchKernelGGL(k_heads, gridFor(E), WG, 0, s, ecanon.p, E, flag.p); }
-	{ ScopedK t(c->timer, "scan(rocprim)"); prim.incScan(flag.p, part->inc.p, E); }
+	{ ScopedK t(c->timer, "scan"); fgprim::scan<u32>(s, flag.p, part->inc.p, E, true, (u32*)B->scratch.p); }
 	const u64 nKeys = fetch(c, part->inc.p + (E - 1));
 	part->ukeys.alloc(nKeys); part->kstart.alloc(nKeys + 1);
 	{
@@ -759,21 +963,220 @@ void buildPart(fg_ctx* c, IndexBuild* B, Prim& prim, u32 binLo, u32 binHi, u64 E
 
 } // namespace
 
+// ---- selection, solid mode ----------------------------------------------------------------------------
+void fgIndexKmerHist(fg_ctx* c, u64* histOut)
+{
+	c->timer.reset();
+	std::vector<u64> h;
+	binHistogram(c, nullptr, binShiftFor(c->k), h);
+	memcpy(histOut, h.data(), FG_INDEX_BINS * 8);
+	c->timer.collect();
+}
+
+void fgIndexCountSlice(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate, float sampleRateInit,
+					   u32 binLo, u32 binHi, u64* distinctOut, u32* nBatchesOut)
+{
+	if (c->k > 17) throw FgError{FG_ERR_KMER_SIZE, "Can't use flat counter for k-mer size > 17"};
+	if (binLo > binHi || binHi > FG_INDEX_BINS) throw FgError{FG_ERR_ARG, "bin range outside [0, 4096]"};
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 n = c->nReads;
+	std::shared_ptr<IndexBuild> B = beginCommon(c);
+	BuildClock clock(c);
+	B->solid = true; B->minCoverage = minFreq; B->minFreq = minFreq; B->repeatRate = repeatRate;
+	B->sampleRateInit = sampleRateInit; B->selectRate = selectRate; B->tandemFreq = tandemFreq;
+	const u64 space = 1ULL << (2 * k);
+	B->cv.keyLo = std::min(space, (u64)binLo << B->binShift);
+	B->cv.keyHi = binHi >= FG_INDEX_BINS ? space : std::min(space, (u64)binHi << B->binShift);
+	const u64 nCnt = B->cv.keyHi - B->cv.keyLo;
+	// k-mer positions whose canonical form falls into the range: what a hashed counter is sized by
+	std::vector<u64> khist;
+	binHistogram(c, nullptr, B->binShift, khist);
+	u64 nInRange = 0;
+	for (u32 b = binLo; b < binHi; ++b) nInRange += khist[b];
+	u64 slots = 1024;
+	while (slots < 2 * nInRange) slots <<= 1;
+	const char* mode = getenv("FG_COUNT_MODE");		// "direct" / "hash": experiments and tests
+	bool hashed = c->totalKmers < (1ULL << FG_COUNT_HBITS) && slots * 8 <= nCnt * 4 / 4;
+	if (mode && !strcmp(mode, "direct")) hashed = false;
+	if (mode && !strcmp(mode, "hash") && c->totalKmers < (1ULL << FG_COUNT_HBITS)) hashed = true;
+	if (hashed)
+	{
+		ScopedK t(c->timer, "memset_counts");
+		B->countTable.alloc(slots);
+		B->cv.table = B->countTable.p;
+		B->cv.mask = slots - 1;
+		HIP_CHECK(hipMemsetAsync(B->countTable.p, 0xFF, slots * 8, s));
+	}
+	else
+	{
+		const u64 chunk = 1ULL << FG_COUNT_CHUNK_BITS;
+		const u64 nChunks = (nCnt + chunk - 1) / chunk;
+		if (nChunks > FG_COUNT_MAX_CHUNKS) throw FgError{FG_ERR_KMER_SIZE, "counter range too wide"};
+		ScopedK t(c->timer, "memset_counts");
+		for (u64 i = 0; i < nChunks; ++i)
+		{
+			const u64 cnt = std::min(chunk, nCnt - i * chunk);
+			B->countChunk[i].alloc(cnt);
+			B->cv.chunk[i] = B->countChunk[i].p;
+			HIP_CHECK(hipMemsetAsync(B->countChunk[i].p, 0, cnt * 4, s));
+		}
+	}
+	if (n)
+	{
+		ScopedK t(c->timer, "k_count");
+		hipLaunchKernelGGL(k_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, k, B->cv, B->scal.p);
+	}
+	B->totalDistinct = fetch(c, (const unsigned long long*)B->scal.p);
+	B->freq.alloc(B->batchCap); B->flags.alloc(B->batchCap); B->thr.alloc(std::max<u32>(1, B->batchReads));
+	if (distinctOut) *distinctOut = B->totalDistinct;
+	if (nBatchesOut) *nBatchesOut = (u32)(B->batchStart.size() - 1);
+	B->seconds = clock.stop();
+	c->indexBuild = B;
+}
+
+static void batchRange(fg_ctx* c, IndexBuild* B, u32 batch, u32& r0, u32& r1)
+{
+	if (!B->solid || B->selectionDone) throw FgError{FG_ERR_STATE, "no solid-mode selection in progress"};
+	if ((size_t)batch + 1 >= B->batchStart.size()) throw FgError{FG_ERR_ARG, "batch index out of range"};
+	r0 = B->batchStart[batch]; r1 = B->batchStart[batch + 1];
+	(void)c;
+}
+
+// frequencies of the batch's k-mer positions as far as THIS context counted them (0 for k-mers outside its key
+// range): device pointer + element count, for the caller to sum over the ranks in place
+void fgIndexBatchFreq(fg_ctx* c, u32 batch, u32** dFreq, u64* nPos)
+{
+	IndexBuild* B = buildState(c);
+	u32 r0, r1;
+	batchRange(c, B, batch, r0, r1);
+	BuildClock clock(c);
+	{
+		ScopedK t(c->timer, "k_freq");
+		hipLaunchKernelGGL(k_freq, r1 - r0, WG, 0, c->stream, r0, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
+						   B->cv, B->freq.p);
+	}
+	if (dFreq) *dFreq = B->freq.p;
+	if (nPos) *nPos = c->hKmerOff[r1] - c->hKmerOff[r0];
+	B->seconds += clock.stop();
+}
+
+// yieldFrequentKmers over the batch's reads from the (complete) frequencies in the batch scratch -> selection bits
+void fgIndexBatchSelect(fg_ctx* c, u32 batch)
+{
+	IndexBuild* B = buildState(c);
+	u32 r0, r1;
+	batchRange(c, B, batch, r0, r1);
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32 nb = r1 - r0;
+	BuildClock clock(c);
+	HIP_CHECK(hipMemsetAsync(B->scal.p + 1, 0, 8, s));
+	{ ScopedK t(c->timer, "k_threshold");
+	  hipLaunchKernelGGL(k_threshold, nb, WG, 0, s, r0, c->dLen.p, c->dKmerOff.p, k, B->freq.p, B->selectRate, B->thr.p); }
+	{ ScopedK t(c->timer, "k_mark");
+	  hipLaunchKernelGGL(k_mark, nb, WG, 0, s, r0, c->dLen.p, c->dKmerOff.p, k, B->freq.p, B->thr.p, B->tandemFreq, B->flags.p,
+						 B->scal.p + 1); }
+	const u64 nCand = fetch(c, (const unsigned long long*)B->scal.p + 1);
+	if (nCand > 0)
+	{
+		u64 slots = 1024;
+		while (slots < 2 * nCand) slots <<= 1;
+		DevBuf<u64> tkeys; DevBuf<u32> tcnt;
+		tkeys.alloc(slots); tcnt.alloc(slots);
+		HIP_CHECK(hipMemsetAsync(tkeys.p, 0xFF, slots * 8, s));
+		HIP_CHECK(hipMemsetAsync(tcnt.p, 0, slots * 4, s));
+		{ ScopedK t(c->timer, "k_tandem_insert");
+		  hipLaunchKernelGGL(k_tandem_insert, nb, WG, 0, s, r0, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+							 B->flags.p, tkeys.p, tcnt.p, slots - 1); }
+		{ ScopedK t(c->timer, "k_tandem_apply");
+		  hipLaunchKernelGGL(k_tandem_apply, nb, WG, 0, s, r0, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
+							 B->flags.p, tkeys.p, tcnt.p, slots - 1, B->tandemFreq); }
+		HIP_CHECK(hipStreamSynchronize(s));
+	}
+	{ ScopedK t(c->timer, "k_accept");
+	  hipLaunchKernelGGL(k_accept, nb, WG, 0, s, r0, c->dLen.p, c->dKmerOff.p, k, B->freq.p, B->minFreq, B->flags.p, B->scal.p + 2); }
+	packBatch(c, B, r0, r1);
+	B->seconds += clock.stop();
+}
+
+void fgIndexSelectionDone(fg_ctx* c, u64* histOut)
+{
+	IndexBuild* B = buildState(c);
+	BuildClock clock(c);
+	B->freq.release(); B->flags.release(); B->thr.release(); B->hashes.release();
+	binHistogram(c, B->bits.p, B->binShift, B->hist);
+	B->selectionDone = true;
+	if (histOut) memcpy(histOut, B->hist.data(), FG_INDEX_BINS * 8);
+	B->seconds += clock.stop();
+}
+
+void fgIndexBeginSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
+					   float sampleRateInit, u64* histOut)
+{
+	u32 nBatches = 0;
+	fgIndexCountSlice(c, minFreq, selectRate, tandemFreq, repeatRate, sampleRateInit, 0, FG_INDEX_BINS, nullptr, &nBatches);
+	for (u32 b = 0; b < nBatches; ++b)
+	{
+		fgIndexBatchFreq(c, b, nullptr, nullptr);
+		fgIndexBatchSelect(c, b);
+	}
+	fgIndexSelectionDone(c, histOut);
+}
+
+// ---- selection, minimizer mode ------------------------------------------------------------------------
+void fgIndexBeginMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, u64* histOut)
+{
+	if (window < 1 || window > MAXW) throw FgError{FG_ERR_ARG, "wrong minimizer length"};
+	hipStream_t s = c->stream;
+	std::shared_ptr<IndexBuild> B = beginCommon(c);
+	BuildClock clock(c);
+	B->solid = false; B->minCoverage = minCoverage; B->repeatRate = repeatRate;
+	B->flags.alloc(B->batchCap);
+	B->hashes.alloc(window == 1 ? 1 : B->batchCap);
+	for (size_t b = 0; b + 1 < B->batchStart.size(); ++b)
+	{
+		const u32 r0 = B->batchStart[b], r1 = B->batchStart[b + 1];
+		{
+			ScopedK t(c->timer, "k_minimizers");
+			hipLaunchKernelGGL(k_minimizers, r1 - r0, WG, 0, s, r0, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
+							   window, B->hashes.p, B->flags.p, B->scal.p + 2);
+		}
+		packBatch(c, B.get(), r0, r1);
+	}
+	HIP_CHECK(hipStreamSynchronize(s));
+	B->flags.release(); B->hashes.release();
+	binHistogram(c, B->bits.p, B->binShift, B->hist);
+	B->selectionDone = true;
+	if (histOut) memcpy(histOut, B->hist.data(), FG_INDEX_BINS * 8);
+	B->seconds = clock.stop();
+	c->indexBuild = B;
+}
+
+// ---- build range / finish --------------------------------------------------------------------------------
 void fgIndexBuildRange(fg_ctx* c, u32 binLo, u32 binHi, unsigned long long* sumsOut)
 {
 	IndexBuild* B = buildState(c);
+	if (!B->selectionDone) throw FgError{FG_ERR_STATE, "the selection is not finished (fg_index_selection_done)"};
 	if (binLo > binHi || binHi > FG_INDEX_BINS) throw FgError{FG_ERR_ARG, "bin range outside [0, 4096]"};
+	if (B->solid && binLo < binHi)
+	{
+		// the finish step asks the counters about the keys of this range (vertex_index.cpp:70-71)
+		const u64 lo = (u64)binLo << B->binShift, hi = binHi >= FG_INDEX_BINS ? (1ULL << (2 * c->k)) : ((u64)binHi << B->binShift);
+		if (lo < B->cv.keyLo || std::min<u64>(hi, 1ULL << (2 * c->k)) > B->cv.keyHi)
+			throw FgError{FG_ERR_ARG, "bin range outside the range this context counted"};
+	}
 	BuildClock clock(c);
-	Prim prim{c};
-	// slices of at most `budget` entries (sort scratch = 4 x 8 bytes per entry of the slice)
-	const u64 budget = getenv("FG_INDEX_SLICE_ENTRIES") ? strtoull(getenv("FG_INDEX_SLICE_ENTRIES"), nullptr, 10) : (768ULL << 20);
+	// slices of at most `budget` entries (sort buffers = 4 x 8 bytes per entry of the slice)
+	const u64 budget = std::min<u64>(fgprim::RS_MAX_N, getenv("FG_INDEX_SLICE_ENTRIES") ? strtoull(getenv("FG_INDEX_SLICE_ENTRIES"), nullptr, 10)
+																						  : (768ULL << 20));
 	u32 lo = binLo;
 	while (lo < binHi)
 	{
 		u32 hi = lo;
 		u64 e = 0;
 		while (hi < binHi && (hi == lo || e + B->hist[hi] <= budget)) { e += B->hist[hi]; ++hi; }
-		buildPart(c, B, prim, lo, hi, e);
+		buildPart(c, B, lo, hi, e);
 		lo = hi;
 	}
 	if (sumsOut) { sumsOut[0] = B->sums[0]; sumsOut[1] = B->sums[1]; }
@@ -786,7 +1189,6 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 	IndexBuild* B = buildState(c);
 	hipStream_t s = c->stream;
 	BuildClock clock(c);
-	Prim prim{c};
 	memset(st, 0, sizeof(*st));
 	const unsigned long long t0 = totalSums ? totalSums[0] : B->sums[0], t1 = totalSums ? totalSums[1] : B->sums[1];
 	// vertex_index.cpp:185-186, the two float operations exactly as written there
@@ -805,7 +1207,7 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 	{
 		ScopedK t(c->timer, "k_classify");
 		hipLaunchKernelGGL(k_classify_count, gridFor(p->nKeys), WG, 0, s, p->ukeys.p, p->kstart.p, p->nKeys, (u64)repFreq,
-						   B->solid ? B->counts.p : (const u32*)nullptr, tot.p);
+						   B->solid ? 1 : 0, B->cv, tot.p);
 	}
 	unsigned long long ht[3];
 	HIP_CHECK(hipMemcpyAsync(ht, tot.p, 24, hipMemcpyDeviceToHost, s));
@@ -824,6 +1226,7 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 		DevBuf<u64> size, off;
 		isRep.alloc(nKeys + 1); keep.alloc(nKeys + 1); repIdx.alloc(nKeys + 1); keepIdx.alloc(nKeys + 1);
 		size.alloc(nKeys + 1); off.alloc(nKeys + 1);
+		B->scratch.reserve(fgprim::scanScratchElems(nKeys + 1) * 8);
 		// one extra zero element so that the exclusive scans also yield the totals
 		HIP_CHECK(hipMemsetAsync(isRep.p + nKeys, 0, 4, s));
 		HIP_CHECK(hipMemsetAsync(keep.p + nKeys, 0, 4, s));
@@ -831,13 +1234,13 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 		{
 			ScopedK t(c->timer, "k_classify");
 			hipLaunchKernelGGL(k_classify, gridFor(nKeys), WG, 0, s, p->ukeys.p, p->kstart.p, nKeys, (u64)repFreq,
-							   B->solid ? B->counts.p : (const u32*)nullptr, isRep.p, keep.p, size.p, err.p);
+							   B->solid ? 1 : 0, B->cv, isRep.p, keep.p, size.p, err.p);
 		}
 		{
-			ScopedK t(c->timer, "scan(rocprim)");
-			prim.excScan(isRep.p, repIdx.p, nKeys + 1);
-			prim.excScan(keep.p, keepIdx.p, nKeys + 1);
-			prim.excScan(size.p, off.p, nKeys + 1);
+			ScopedK t(c->timer, "scan");
+			fgprim::scan<u32>(s, isRep.p, repIdx.p, nKeys + 1, false, (u32*)B->scratch.p);
+			fgprim::scan<u32>(s, keep.p, keepIdx.p, nKeys + 1, false, (u32*)B->scratch.p);
+			fgprim::scan<u64>(s, size.p, off.p, nKeys + 1, false, (u64*)B->scratch.p);
 		}
 		const u64 pRep = fetch(c, repIdx.p + nKeys), pKeep = fetch(c, keepIdx.p + nKeys), pEnt = fetch(c, off.p + nKeys);
 		{
@@ -858,9 +1261,13 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 	if (keepBase != nKeep || repBase != nRep || entBase != nEnt) throw FgError{FG_ERR_HIP, "internal: part totals disagree"};
 	if (fetch(c, err.p)) { clearIndex(c); throw FgError{FG_ERR_KMER_TOO_FREQUENT, "k-mer is too frequent"}; }
 	HIP_CHECK(hipMemcpyAsync(c->dKeyOff.p + nKeep, &nEnt, 8, hipMemcpyHostToDevice, s));
-	B->counts.release();
+	for (auto& ch : B->countChunk) ch.release();
+	B->countTable.release();
+	B->scratch.release();
 	c->nKeys = nKeep; c->nEntries = nEnt; c->nRep = nRep;
-	fgIndexLookupStructures(c, B->flags.p);
+	// the selection bits become the "owns an entry" bits, in place
+	c->dIndexedBits.swap(B->bits);
+	fgIndexLookupStructures(c, true);
 	st->selected_kmers = nKeep;
 	st->index_entries = nEnt;
 	st->repetitive_kmers = nRep;
@@ -878,8 +1285,9 @@ void fgIndexFinish(fg_ctx* c, const unsigned long long* totalSums, fg_index_stat
 }
 
 // probe table (load <= 0.5) + one "owns an entry" bit per forward k-mer position, from the CSR arrays in
-// the context.  flags: the build's per-position selection, or null (imported index: the lists are searched)
-void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags)
+// the context.  bitsHoldSelection: c->dIndexedBits holds the build's selection bits (cleared in place where a
+// selected position's k-mer left the index); otherwise (imported index) the lists are searched
+void fgIndexLookupStructures(fg_ctx* c, bool bitsHoldSelection)
 {
 	hipStream_t s = c->stream;
 	const u64 nKeep = c->nKeys, nRep = c->nRep;
@@ -941,114 +1349,33 @@ void fgIndexLookupStructures(fg_ctx* c, const uint8_t* flags)
 			hipLaunchKernelGGL(k_table_insert<false>, gridFor(nKeep + nRep), WG, 0, s, c->dKeys.p, c->dKeyOff.p, nKeep,
 							   c->dRepKeys.p, nRep, T, c->dTable.p, (ulonglong2*)nullptr);
 	}
-	c->dIndexedBits.alloc((c->totalKmers + 31) / 32 + 1);
-	HIP_CHECK(hipMemsetAsync(c->dIndexedBits.p, 0, c->dIndexedBits.bytes(), s));
+	const u64 bitWords = (c->totalKmers + 31) / 32 + 1;
+	if (!bitsHoldSelection || c->dIndexedBits.n < bitWords)
+	{
+		bitsHoldSelection = false;
+		c->dIndexedBits.alloc(bitWords);
+		HIP_CHECK(hipMemsetAsync(c->dIndexedBits.p, 0, c->dIndexedBits.bytes(), s));
+	}
 	if (c->nReads && c->totalKmers)
 	{
 		ScopedK t(c->timer, "k_indexed_bits");
-		hipLaunchKernelGGL(k_indexed_bits, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, c->k,
-						   flags, c->table, c->tableWide ? 1 : 0, c->dEntries.p, c->dIndexedBits.p);
+		if (bitsHoldSelection)
+		{
+			if (wide) hipLaunchKernelGGL(k_indexed_clear<true>, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p,
+										 c->dKmerOff.p, c->k, c->table, c->dIndexedBits.p);
+			else hipLaunchKernelGGL(k_indexed_clear<false>, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p,
+									c->dKmerOff.p, c->k, c->table, c->dIndexedBits.p);
+		}
+		else
+		{
+			if (wide) hipLaunchKernelGGL(k_indexed_search<true>, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p,
+										 c->dKmerOff.p, c->k, c->table, c->dEntries.p, c->dIndexedBits.p);
+			else hipLaunchKernelGGL(k_indexed_search<false>, c->nReads, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p,
+									c->dKmerOff.p, c->k, c->table, c->dEntries.p, c->dIndexedBits.p);
+		}
 	}
 	HIP_CHECK(hipStreamSynchronize(s));
 	c->indexBuilt = true;
-}
-
-void fgIndexBeginSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
-					   float sampleRateInit, u64* histOut)
-{
-	if (c->k > 17) throw FgError{FG_ERR_KMER_SIZE, "Can't use flat counter for k-mer size > 17"};
-	hipStream_t s = c->stream;
-	const int k = c->k;
-	const u32 n = c->nReads;
-	clearIndex(c);
-	c->timer.reset();
-	c->indexBuild.reset();
-	std::shared_ptr<IndexBuild> B(new IndexBuild);
-	BuildClock clock(c);
-	B->solid = true; B->minCoverage = minFreq; B->repeatRate = repeatRate; B->sampleRateInit = sampleRateInit;
-	B->posBits = bitsFor((u64)c->maxLen);
-
-	const u64 space = 1ULL << (2 * k);
-	B->counts.alloc(space);
-	DevBuf<unsigned long long> scal;	// [0] distinct, [1] tandem candidates, [2] accepted
-	scal.alloc(4);
-	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
-	{ ScopedK t(c->timer, "memset_counts"); HIP_CHECK(hipMemsetAsync(B->counts.p, 0, space * 4, s)); }
-	DevBuf<u32> freq, thr;
-	freq.alloc(c->totalKmers); B->flags.alloc(c->totalKmers); thr.alloc(n);
-	if (n)
-	{
-		{ ScopedK t(c->timer, "k_count");
-		  hipLaunchKernelGGL(k_count, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, k, B->counts.p, scal.p); }
-		{ ScopedK t(c->timer, "k_freq");
-		  hipLaunchKernelGGL(k_freq, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k, B->counts.p, freq.p); }
-		{ ScopedK t(c->timer, "k_threshold");
-		  hipLaunchKernelGGL(k_threshold, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, selectRate, thr.p); }
-		{ ScopedK t(c->timer, "k_mark");
-		  hipLaunchKernelGGL(k_mark, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, thr.p, tandemFreq, B->flags.p, scal.p + 1); }
-	}
-	unsigned long long h[4];
-	HIP_CHECK(hipMemcpyAsync(h, scal.p, 32, hipMemcpyDeviceToHost, s));
-	HIP_CHECK(hipStreamSynchronize(s));
-	B->totalDistinct = h[0];
-	if (h[1] > 0)
-	{
-		u64 slots = 1024;
-		while (slots < 2 * h[1]) slots <<= 1;
-		DevBuf<u64> tkeys; DevBuf<u32> tcnt;
-		tkeys.alloc(slots); tcnt.alloc(slots);
-		HIP_CHECK(hipMemsetAsync(tkeys.p, 0xFF, slots * 8, s));
-		HIP_CHECK(hipMemsetAsync(tcnt.p, 0, slots * 4, s));
-		{ ScopedK t(c->timer, "k_tandem_insert");
-		  hipLaunchKernelGGL(k_tandem_insert, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							 B->flags.p, tkeys.p, tcnt.p, slots - 1); }
-		{ ScopedK t(c->timer, "k_tandem_apply");
-		  hipLaunchKernelGGL(k_tandem_apply, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							 B->flags.p, tkeys.p, tcnt.p, slots - 1, tandemFreq); }
-		HIP_CHECK(hipStreamSynchronize(s));
-	}
-	if (n)
-	{
-		ScopedK t(c->timer, "k_accept");
-		hipLaunchKernelGGL(k_accept, n, WG, 0, s, c->dLen.p, c->dKmerOff.p, k, freq.p, minFreq, B->flags.p, scal.p + 2);
-	}
-	freq.release();
-	binHistogram(c, B.get(), histOut);
-	B->seconds = clock.stop();
-	c->indexBuild = B;
-}
-
-void fgIndexBeginMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeatRate, u64* histOut)
-{
-	if (window < 1 || window > MAXW) throw FgError{FG_ERR_ARG, "wrong minimizer length"};
-	hipStream_t s = c->stream;
-	const int k = c->k;
-	const u32 n = c->nReads;
-	clearIndex(c);
-	c->timer.reset();
-	c->indexBuild.reset();
-	std::shared_ptr<IndexBuild> B(new IndexBuild);
-	BuildClock clock(c);
-	B->solid = false; B->minCoverage = minCoverage; B->repeatRate = repeatRate;
-	B->posBits = bitsFor((u64)c->maxLen);
-	DevBuf<unsigned long long> scal;
-	scal.alloc(4);
-	HIP_CHECK(hipMemsetAsync(scal.p, 0, 32, s));
-	B->flags.alloc(c->totalKmers);
-	{
-		DevBuf<u64> hashes;
-		hashes.alloc(window == 1 ? 1 : c->totalKmers);
-		if (n)
-		{
-			ScopedK t(c->timer, "k_minimizers");
-			hipLaunchKernelGGL(k_minimizers, n, WG, 0, s, c->dWords.p, c->dWordOff.p, c->dLen.p, c->dKmerOff.p, k,
-							   window, hashes.p, B->flags.p, scal.p + 2);
-		}
-		HIP_CHECK(hipStreamSynchronize(s));
-	}
-	binHistogram(c, B.get(), histOut);
-	B->seconds = clock.stop();
-	c->indexBuild = B;
 }
 
 void fgBuildIndexSolid(fg_ctx* c, i32 minFreq, float selectRate, i32 tandemFreq, float repeatRate,
@@ -1064,6 +1391,23 @@ void fgBuildIndexMinimizers(fg_ctx* c, i32 minCoverage, i32 window, float repeat
 	fgIndexBeginMinimizers(c, minCoverage, window, repeatRate, nullptr);
 	fgIndexBuildRange(c, 0, FG_INDEX_BINS, nullptr);
 	fgIndexFinish(c, nullptr, st);
+}
+
+// the CSR arrays in the context must be well formed before lists are read through them
+static void checkCsr(fg_ctx* c)
+{
+	DevBuf<u32> bad;
+	bad.alloc(1);
+	HIP_CHECK(hipMemsetAsync(bad.p, 0, 4, c->stream));
+	{
+		ScopedK t(c->timer, "k_check_csr");
+		hipLaunchKernelGGL(k_check_csr, gridFor(c->nKeys + 1), WG, 0, c->stream, c->dKeys.p, c->dKeyOff.p, c->nKeys, c->nEntries, bad.p);
+	}
+	if (fetch(c, bad.p))
+	{
+		clearIndex(c);
+		throw FgError{FG_ERR_ARG, "malformed index arrays: key_off must start at 0, never decrease and end at n_entries; keys must ascend"};
+	}
 }
 
 // An index given as CSR arrays (host or device memory): what a rank assembles from the all-gathered pieces
@@ -1084,6 +1428,39 @@ void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64
 	if (nRep) HIP_CHECK(hipMemcpyAsync(c->dRepKeys.p, repKeys, nRep * 8, kind, s));
 	c->nKeys = nKeys; c->nEntries = nEnt; c->nRep = nRep;
 	c->sampleRate = sampleRate;
-	fgIndexLookupStructures(c, nullptr);
+	checkCsr(c);
+	fgIndexLookupStructures(c, false);
+	c->timer.collect();
+}
+
+// The all-gather of a sharded build without a second copy of the index: this context's own piece (what finish left)
+// is set aside, the context's arrays become the full-size ones, and the caller's collective writes every rank's
+// piece -- its own included -- straight into them (full[0..3] = keys, key_off, entries, repetitive keys;
+// piece[0..3] the same of the own piece, pieceSizes = {keys, entries, repetitive}).  fgIndexGatherEnd frees the
+// piece, checks the arrays and builds the lookup structures.
+void fgIndexGatherBegin(fg_ctx* c, u64 nKeys, u64 nEntries, u64 nRep, u64** full, u64** piece, u64* pieceSizes)
+{
+	if (!c->indexBuilt || c->gathering) throw FgError{FG_ERR_STATE, "gather needs a finished piece (fg_index_finish)"};
+	c->timer.reset();
+	c->indexBuilt = false;
+	c->dTable.release(); c->dIndexedBits.release();
+	c->gKeys.swap(c->dKeys); c->gKeyOff.swap(c->dKeyOff); c->gEntries.swap(c->dEntries); c->gRepKeys.swap(c->dRepKeys);
+	c->gNKeys = c->nKeys; c->gNEntries = c->nEntries; c->gNRep = c->nRep;
+	c->dKeys.alloc(nKeys); c->dKeyOff.alloc(nKeys + 1); c->dEntries.alloc(nEntries); c->dRepKeys.alloc(nRep);
+	c->nKeys = nKeys; c->nEntries = nEntries; c->nRep = nRep;
+	c->gathering = true;
+	full[0] = c->dKeys.p; full[1] = c->dKeyOff.p; full[2] = c->dEntries.p; full[3] = c->dRepKeys.p;
+	piece[0] = c->gKeys.p; piece[1] = c->gKeyOff.p; piece[2] = c->gEntries.p; piece[3] = c->gRepKeys.p;
+	pieceSizes[0] = c->gNKeys; pieceSizes[1] = c->gNEntries; pieceSizes[2] = c->gNRep;
+}
+
+void fgIndexGatherEnd(fg_ctx* c, float sampleRate)
+{
+	if (!c->gathering) throw FgError{FG_ERR_STATE, "no gather in progress"};
+	c->gathering = false;
+	c->gKeys.release(); c->gKeyOff.release(); c->gEntries.release(); c->gRepKeys.release();
+	c->sampleRate = sampleRate;
+	checkCsr(c);
+	fgIndexLookupStructures(c, false);
 	c->timer.collect();
 }

@@ -1,19 +1,20 @@
 """Multi-GPU layout of the path (option A): one process per GPU.
 
-* INDEX BUILD, sharded by key range.  Every rank runs the k-mer selection over all reads (it needs every
-  read: exact counts, per-read thresholds / minimizers) and gets the same histogram of accepted positions
-  per key bin; ``balanced_bin_ranges`` cuts the bins into ``world`` contiguous ranges of about equal size;
-  rank r sorts and run-length encodes only its range (``fg_index_build_range``).  Two collectives:
-  an all-reduce of filterFrequentKmers' two integer sums (vertex_index.cpp:175-184 takes them over ALL
-  keys), then an all-gather of the CSR pieces -- keys, list offsets, entries, repetitive keys, in rank
-  order = key order -- after which every rank imports the concatenation (``fg_import_index``) and holds
-  the full index.  With the nccl backend (= RCCL over xGMI) the pieces travel device to device.
+* INDEX BUILD, sharded by key range (``build_index_sharded``).  ``balanced_bin_ranges`` cuts the 4096 key bins
+  into ``world`` contiguous ranges of about equal weight; rank r holds the exact k-mer counters of ITS range only,
+  sorts and run-length encodes only its range.  Collectives: an all-reduce of the k-mer frequencies per batch of
+  reads (solid mode: each rank knows the counts of its own key range), an all-reduce of filterFrequentKmers' two
+  integer sums (vertex_index.cpp:175-184 takes them over ALL keys), then an all-gather of the CSR pieces -- keys,
+  list offsets, entries, repetitive keys, in rank order = key order -- straight into every rank's own full-size
+  index arrays (``fg_index_gather_begin / _end``).  With the nccl backend (= RCCL over xGMI) everything travels
+  device to device.
 * OVERLAP STAGE: reads shard by sequence id, rank r owns the forward reads i with i % world == r and
   computes their lists against its full index copy: no data-path collective; only the barrier / max-time
   reduction of the bench.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -110,56 +111,148 @@ def allgather_pieces(piece, rank: int, world: int, dev):
 class _DevArr:
     """device memory as a ``__cuda_array_interface__`` object (torch wraps it without copying)"""
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _view(ptr: int, n: int, cuda_dev, typestr="<i8"):
+    """torch tensor over n elements of device memory at ptr (no copy)"""
+    import torch
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=torch.int64 if typestr == "<i8" else torch.int32, device=cuda_dev)
+    return torch.as_tensor(_DevArr(ptr, n, typestr), device=cuda_dev)
+
+
+def _all_reduce_dev(t, on_device: bool):
+    """sum over the ranks, in place, of a device tensor: RCCL on the tensor itself, or (gloo rehearsal) through a
+    host copy"""
+    import torch.distributed as td
+    if on_device:
+        td.all_reduce(t)
+    else:
+        h = t.cpu()
+        td.all_reduce(h)
+        t.copy_(h)
+
+
+def _broadcast_dev(t, src: int, on_device: bool):
+    import torch.distributed as td
+    if t.numel() == 0:
+        return
+    if on_device:
+        td.broadcast(t, src=src)
+    else:
+        h = t.cpu()
+        td.broadcast(h, src=src)
+        t.copy_(h)
+
+
+def gather_pieces_inplace(vi, rank: int, world: int, on_device: bool, sample_rate_of, force=False):
+    """All-gather of the ranks' CSR pieces (ascending key ranges in rank order) straight into the context's own
+    full-size arrays (fg_index_gather_begin / _end): no second copy of the index.  Pieces differ in size: their sizes
+    are exchanged first, then every rank broadcasts its slice (a ring all-gather's volume, no padding).
+    ``sample_rate_of(E)`` gives VertexIndex::getSampleRate() for the whole index.  Returns ((K, E, R), bytes moved)."""
+    import torch
+    import torch.distributed as td
+    cuda = torch.device("cuda", torch.cuda.current_device())
+    red = cuda if on_device else torch.device("cpu")
+    (nk, ne, nr), _ = vi.device_arrays()
+    sizes = torch.zeros((world, 3), dtype=torch.int64, device=red)
+    sizes[rank] = torch.tensor([nk, ne, nr], dtype=torch.int64, device=red)
+    if world > 1 or force:
+        td.all_reduce(sizes)
+    sz = sizes.cpu().numpy()
+    K, E, R = (int(x) for x in sz.sum(axis=0))
+    kb = np.concatenate([[0], np.cumsum(sz[:, 0])]).astype(np.int64)
+    eb = np.concatenate([[0], np.cumsum(sz[:, 1])]).astype(np.int64)
+    rb = np.concatenate([[0], np.cumsum(sz[:, 2])]).astype(np.int64)
+    full, piece, psz = vi.gather_begin(K, E, R)
+    assert psz == [nk, ne, nr]
+    keys, off, ent, rep = _view(full[0], K, cuda), _view(full[1], K + 1, cuda), _view(full[2], E, cuda), _view(full[3], R, cuda)
+    pk, po, pe, pr = _view(piece[0], nk, cuda), _view(piece[1], nk + 1, cuda), _view(piece[2], ne, cuda), _view(piece[3], nr, cuda)
+    if nk:
+        keys[kb[rank]:kb[rank + 1]] = pk
+        off[kb[rank]:kb[rank + 1]] = po[:nk] + int(eb[rank])     # list offsets shift by the entries of the pieces before
+    if ne:
+        ent[eb[rank]:eb[rank + 1]] = pe
+    if nr:
+        rep[rb[rank]:rb[rank + 1]] = pr
+    off[K:K + 1] = E
+    moved = world * 24
+    if world > 1 or force:
+        for r in range(world):
+            for arr, b in ((keys, kb), (off, kb), (ent, eb), (rep, rb)):
+                if b[r + 1] > b[r]:
+                    _broadcast_dev(arr[b[r]:b[r + 1]], r, on_device)
+                    moved += int(b[r + 1] - b[r]) * 8
+    torch.cuda.synchronize()
+    vi.gather_end(sample_rate_of(E))
+    vi.stats = dict(vi.stats or {}, selected_kmers=K, index_entries=E, repetitive_kmers=R,
+                    sample_rate=float(np.float32(sample_rate_of(E))))
+    return (K, E, R), moved
 
 
 def build_index_sharded(vi, cfg: dict, rank: int, world: int, on_device: bool):
-    """The build main_assemble.cpp:195-223 selects, sharded over the ranks of the default process group.
-    ``on_device``: collectives on device tensors (nccl = RCCL); otherwise through host tensors (gloo).
+    """The build main_assemble.cpp:195-223 selects, sharded over the ranks of the default process group
+    (SURVEY.md §8e).  ``on_device``: collectives on device memory (nccl = RCCL over xGMI); otherwise through host
+    copies (gloo rehearsal).
+
+    * solid k-mers: the key bins are cut into ``world`` ranges holding equal numbers of k-mer positions
+      (``fg_index_kmer_hist``, identical on every rank); rank r keeps the exact counters of ITS range only (an
+      eighth of the 4^k array at 8 ranks) and counts those k-mers over all reads; then, batch of reads by batch
+      (bounded scratch), every rank writes the frequencies it knows, an all-reduce makes the array complete, and
+      every rank runs the per-read selection on it (replicated: it is cheap and leaves every rank with the same
+      selection bits, so nothing else of the selection is exchanged);
+    * minimizers: the selection needs no counters and no exchange; ranges are balanced on the accepted positions;
+    * rank r sorts and run-length encodes its range (the same range its counters cover); all-reduce of
+      filterFrequentKmers' two sums; finish; all-gather of the CSR pieces in place.
     Returns the index statistics plus what the collectives moved."""
     import torch
     import torch.distributed as td
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    cuda = torch.device("cuda", torch.cuda.current_device())
+    red = cuda if on_device else torch.device("cpu")
+    # FLYE_FORCE_COLLECTIVES: run every collective also in a one-rank group (tools/sharded_build_check.py: one rank
+    # on a one-GPU box then exercises every RCCL call of this path)
+    coll = world > 1 or bool(os.environ.get("FLYE_FORCE_COLLECTIVES"))
     t0 = time.perf_counter()
-    hist = vi.begin(cfg)
-    ranges = balanced_bin_ranges(hist, world)
+    freq_bytes = 0
+    distinct = 0
+    if cfg["use_minimizers"]:
+        hist = vi.begin(cfg)
+        ranges = balanced_bin_ranges(hist, world)
+    else:
+        ranges = balanced_bin_ranges(vi.kmer_hist(), world)
+        distinct, n_batches = vi.count_slice(cfg, *ranges[rank])
+        for b in range(n_batches):
+            ptr, n = vi.batch_freq(b)
+            if coll and n:
+                _all_reduce_dev(_view(ptr, n, cuda, "<i4"), on_device)
+                freq_bytes += 4 * n
+            vi.batch_select(b)
+        vi.selection_done()
     sums = vi.build_range(*ranges[rank])
     t1 = time.perf_counter()
-    tot = torch.tensor(sums.astype(np.int64), device=dev)
-    td.all_reduce(tot)
-    st = dict(vi.finish(tot.cpu().numpy().astype(np.uint64)))
+    tot = torch.tensor(np.concatenate([sums.astype(np.int64), [distinct]]), device=red)
+    if coll:
+        td.all_reduce(tot)
+    tot = tot.cpu().numpy()
+    st = dict(vi.finish(tot[:2].astype(np.uint64)))
+    st["total_kmers"] = int(tot[2])
+    (nk, ne, nr), _ = vi.device_arrays()
     t2 = time.perf_counter()
+    total_bases = np.float32(vi.ctx.rs.total_bases)
 
-    (nk, ne, nr), ptrs = vi.device_arrays()
-    if on_device:
-        def view(ptr, n):
-            return torch.as_tensor(_DevArr(ptr, n), device=dev) if n else torch.empty(0, dtype=torch.int64, device=dev)
-        piece = (view(ptrs[0], nk), view(ptrs[1], nk + 1), view(ptrs[2], ne), view(ptrs[3], nr))
-    else:
-        ex = vi.export()
-        piece = tuple(torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
-                      for a in (ex.keys, ex.key_off, ex.entries, ex.repetitive))
-    keys, off, ent, rep, (K, E, R), moved = allgather_pieces(piece, rank, world, dev)
-    if on_device:
-        torch.cuda.synchronize()
+    def sample_rate_of(E):
+        # VertexIndex::getSampleRate(): the ctor value, or totalLen / totalEntries over the WHOLE index (vertex_index.cpp:480-482)
+        if cfg["use_minimizers"]:
+            return float(total_bases / np.float32(E)) if E else float("inf")
+        return vi._sample_rate_init
+
+    (K, E, R), moved = gather_pieces_inplace(vi, rank, world, on_device, sample_rate_of, force=coll)
     t3 = time.perf_counter()
-    # VertexIndex::getSampleRate(): the ctor value, or totalLen / totalEntries over the WHOLE index (vertex_index.cpp:480-482)
-    if cfg["use_minimizers"]:
-        sample_rate = float(np.float32(vi.ctx.rs.total_bases) / np.float32(E)) if E else float("inf")
-    else:
-        sample_rate = vi._sample_rate_init
-    if on_device:
-        vi.import_index((K, E, R), sample_rate, on_device=True,
-                        ptrs=(keys.data_ptr(), off.data_ptr(), ent.data_ptr(), rep.data_ptr()))
-    else:
-        from .gpu import IndexExport
-        vi.import_index(IndexExport(keys[:K].numpy().view(np.uint64), off.numpy().view(np.uint64),
-                                    ent[:E].numpy().view(np.uint64), rep[:R].numpy().view(np.uint64)), sample_rate)
-    t4 = time.perf_counter()
-    st.update(selected_kmers=K, index_entries=E, repetitive_kmers=R, sample_rate=float(np.float32(sample_rate)),
-              bin_range=ranges[rank], piece=(int(nk), int(ne), int(nr)),
-              collective_bytes=moved + 16, select_and_sort_s=t1 - t0, finish_s=t2 - t1,
-              allgather_s=t3 - t2, import_s=t4 - t3, build_seconds=t4 - t0)
+    st.update(vi.stats)
+    st.update(bin_range=ranges[rank], piece=(int(nk), int(ne), int(nr)),
+              collective_bytes=moved + 24 + freq_bytes, freq_allreduce_bytes=freq_bytes,
+              select_and_sort_s=t1 - t0, finish_s=t2 - t1, allgather_s=t3 - t2, import_s=0.0, build_seconds=t3 - t0)
     vi.stats = st
     return st

@@ -39,6 +39,8 @@ REC_DTYPE = np.dtype([("cur_id", "<u4"), ("ext_id", "<u4"), ("cur_begin", "<i4")
 ABI_SYMBOLS = ["fg_abi_version", "fg_create", "fg_destroy", "fg_strerror", "fg_last_error",
                "fg_container_info", "fg_set_reads", "fg_set_queries", "fg_build_index_solid", "fg_build_index_minimizers",
                "fg_index_begin_solid", "fg_index_begin_minimizers", "fg_index_build_range", "fg_index_finish",
+               "fg_index_kmer_hist", "fg_index_count_slice", "fg_index_batch_freq", "fg_index_batch_select",
+               "fg_index_selection_done", "fg_index_gather_begin", "fg_index_gather_end", "fg_memory_stats",
                "fg_import_index", "fg_index_device_arrays", "fg_clear_index", "fg_export_index", "fg_overlaps", "fg_release_batch",
                "fg_kernel_times", "fg_debug_sort_pairs", "fg_debug_edit_distances", "fg_align_cigar_ksw", "fg_release_cigars"]
 
@@ -101,6 +103,15 @@ def load_library():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise FlyeGpuError(-100, f"{LIB_PATH} not built: run __graft_entry__.build()")
+        # One HIP runtime per process.  torch ships its own copy of libamdhip64 / libhsa-runtime64; a Python
+        # process that uses both this library and torch.cuda (flye_amd/dist.py wraps context memory as torch
+        # tensors for the collectives) must load torch's FIRST -- the other order leaves torch with "No HIP GPUs
+        # are available" (measured: pytest process, library loaded before the first torch.cuda call).  A C / C++
+        # consumer of the C ABI never sees torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.fg_abi_version.restype = C.c_int
         L.fg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int]
@@ -119,6 +130,15 @@ def load_library():
         L.fg_index_begin_minimizers.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
         L.fg_index_build_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.fg_index_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(IndexStats)]
+        L.fg_index_kmer_hist.argtypes = [C.c_void_p, C.c_void_p]
+        L.fg_index_count_slice.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_uint32,
+                                           C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        L.fg_index_batch_freq.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.fg_index_batch_select.argtypes = [C.c_void_p, C.c_uint32]
+        L.fg_index_selection_done.argtypes = [C.c_void_p, C.c_void_p]
+        L.fg_index_gather_begin.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.fg_index_gather_end.argtypes = [C.c_void_p, C.c_float]
+        L.fg_memory_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
         L.fg_import_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                       C.c_void_p, C.c_float, C.c_int]
         L.fg_index_device_arrays.argtypes = [C.c_void_p] + [C.c_void_p] * 7
@@ -233,6 +253,13 @@ class OverlapResult:
             cnt, dg = self.match_digests()
             out = [f"{l} {cnt[i]} {int(dg[i]):016x}" for i, l in enumerate(out)]
         return out
+
+
+def memory_stats(reset_peak=False):
+    """(device bytes the library holds now, peak since the last reset) over all contexts of the process"""
+    now, peak = C.c_uint64(), C.c_uint64()
+    load_library().fg_memory_stats(C.byref(now), C.byref(peak), 1 if reset_peak else 0)
+    return now.value, peak.value
 
 
 class Context:
@@ -391,6 +418,48 @@ class VertexIndex:
                                                    int(cfg["meta_read_filter_kmer_freq"]), cfg["repeat_kmer_rate"],
                                                    self._sample_rate_init, hist.ctypes.data))
         return hist
+
+    # solid-mode selection in steps of its own (counters of a key range only; batches of reads)
+    def kmer_hist(self) -> np.ndarray:
+        """ALL k-mer positions per key bin (what the ranks' key ranges are balanced on)."""
+        hist = np.zeros(self.INDEX_BINS, np.uint64)
+        self.ctx._check(self.ctx.L.fg_index_kmer_hist(self.ctx.h, hist.ctypes.data))
+        return hist
+
+    def count_slice(self, cfg: dict, bin_lo: int, bin_hi: int):
+        """-> (distinct canonical k-mers of the range, number of read batches)"""
+        self.countKmers()
+        d, nb = C.c_uint64(), C.c_uint32()
+        self.ctx._check(self.ctx.L.fg_index_count_slice(self.ctx.h, 2, cfg["meta_read_top_kmer_rate"],
+                                                        int(cfg["meta_read_filter_kmer_freq"]), cfg["repeat_kmer_rate"],
+                                                        self._sample_rate_init, int(bin_lo), int(bin_hi), C.byref(d), C.byref(nb)))
+        return d.value, nb.value
+
+    def batch_freq(self, batch: int):
+        """-> (device pointer of the batch's uint32 frequencies, their number)"""
+        p, n = C.c_void_p(), C.c_uint64()
+        self.ctx._check(self.ctx.L.fg_index_batch_freq(self.ctx.h, int(batch), C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def batch_select(self, batch: int):
+        self.ctx._check(self.ctx.L.fg_index_batch_select(self.ctx.h, int(batch)))
+
+    def selection_done(self) -> np.ndarray:
+        hist = np.zeros(self.INDEX_BINS, np.uint64)
+        self.ctx._check(self.ctx.L.fg_index_selection_done(self.ctx.h, hist.ctypes.data))
+        return hist
+
+    def gather_begin(self, n_keys: int, n_entries: int, n_rep: int):
+        """-> (full array device pointers [keys, key_off, entries, repetitive], the own piece's, piece sizes
+        (keys, entries, repetitive))"""
+        full = (C.c_void_p * 4)()
+        piece = (C.c_void_p * 4)()
+        sizes = (C.c_uint64 * 3)()
+        self.ctx._check(self.ctx.L.fg_index_gather_begin(self.ctx.h, int(n_keys), int(n_entries), int(n_rep), full, piece, sizes))
+        return [x or 0 for x in full], [x or 0 for x in piece], [int(x) for x in sizes]
+
+    def gather_end(self, sample_rate: float):
+        self.ctx._check(self.ctx.L.fg_index_gather_end(self.ctx.h, float(sample_rate)))
 
     def build_range(self, bin_lo: int, bin_hi: int) -> np.ndarray:
         sums = np.zeros(2, np.uint64)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 3
+#define FG_ABI_VERSION 4
 
 enum {
 	FG_OK = 0,
@@ -133,9 +133,53 @@ int fg_index_begin_minimizers(fg_ctx* ctx, int32_t min_coverage, int32_t window,
 int fg_index_build_range(fg_ctx* ctx, uint32_t bin_lo, uint32_t bin_hi, uint64_t* sums);
 int fg_index_finish(fg_ctx* ctx, const uint64_t* total_sums, struct fg_index_stats* out);
 
+/* The solid-mode selection in steps of its own: bounded memory on one GPU, and on several GPUs the exact counters
+ * -- the 4^k * 4 B array that KmerCounter's flat array + overflow map become (vertex_index.cpp:499-616) -- held
+ * only for a rank's own key range ("GPU g counts only canonical k-mers [of its slice] over all
+ * reads"):
+ *   kmer_hist       hist[FG_INDEX_BINS] = ALL k-mer positions per key bin: what the ranks' key ranges are balanced
+ *                   on before anything is selected (the same ranges then serve fg_index_build_range);
+ *   count_slice     allocates the counters of bins [bin_lo, bin_hi) and counts those k-mers over all reads;
+ *                   *distinct = this range's share of "Total k-mers" (vertex_index.cpp:589; adds up over ranks);
+ *                   *n_batches = the batches of reads the selection then runs in (<= FG_INDEX_BATCH_KMERS k-mer
+ *                   positions each, default 2^28: the selection's scratch is bounded by that, not by the read set);
+ *   batch_freq      KmerCounter::getFreq of every k-mer position of batch b as far as THIS context counted it (0
+ *                   outside its range) into a device array (*d_freq, *n uint32): summed over the ranks in place
+ *                   (all-reduce) it is the complete array; on one GPU it already is;
+ *   batch_select    yieldFrequentKmers (vertex_index.cpp:316-358) over the batch's reads from that array;
+ *   selection_done  releases the batch scratch; hist[] as fg_index_begin_solid gives it.
+ * fg_index_begin_solid = count_slice(0, FG_INDEX_BINS) + {batch_freq, batch_select} per batch + selection_done.
+ * fg_index_build_range then accepts only bins inside the counted range (the finish step asks the counters
+ * about the keys it built, vertex_index.cpp:70-71). */
+int fg_index_kmer_hist(fg_ctx* ctx, uint64_t* hist);
+int fg_index_count_slice(fg_ctx* ctx, int32_t min_freq, float select_rate, int32_t tandem_freq, float repeat_rate,
+                         float sample_rate_init, uint32_t bin_lo, uint32_t bin_hi, uint64_t* distinct,
+                         uint32_t* n_batches);
+int fg_index_batch_freq(fg_ctx* ctx, uint32_t batch, uint32_t** d_freq, uint64_t* n);
+int fg_index_batch_select(fg_ctx* ctx, uint32_t batch);
+int fg_index_selection_done(fg_ctx* ctx, uint64_t* hist);
+
+/* The all-gather of a sharded build without a second copy of the index.  After fg_index_finish the context holds
+ * its own piece.  gather_begin sets that piece aside and makes the context's arrays the full-size ones
+ * (n_keys, n_entries, n_repetitive = the totals over the ranks); full[4] / piece[4] receive the DEVICE pointers
+ * of {keys, key_off (n_keys + 1), entries, repetitive keys} of the full arrays and of the own piece,
+ * piece_sizes[3] = {keys, entries, repetitive} of the piece.  The caller's collective writes every rank's piece
+ * -- the own one included, list offsets shifted by the entries of the pieces before -- straight into the full
+ * arrays; gather_end frees the piece, checks the arrays (FG_ERR_ARG when offsets or keys are out of order) and
+ * builds the lookup structures. */
+int fg_index_gather_begin(fg_ctx* ctx, uint64_t n_keys, uint64_t n_entries, uint64_t n_repetitive,
+                          uint64_t** full, uint64_t** piece, uint64_t* piece_sizes);
+int fg_index_gather_end(fg_ctx* ctx, float sample_rate);
+
+/* Device bytes this library holds right now and at most since the last reset (all contexts of the process;
+ * every device allocation of the library is counted); reset_peak != 0 restarts the peak at the current value. */
+int fg_memory_stats(uint64_t* bytes_now, uint64_t* bytes_peak, int reset_peak);
+
 /* An index given as CSR arrays in the layout fg_export_index writes (keys ascending, key_off[n_keys + 1],
  * entries ascending per key), in host memory or -- on_device != 0 -- in this context's device memory
- * (e.g. torch tensors filled by an RCCL all-gather).  sample_rate = VertexIndex::getSampleRate(). */
+ * (e.g. torch tensors filled by an RCCL all-gather).  sample_rate = VertexIndex::getSampleRate().
+ * The arrays are checked on the device (offsets start at 0, never decrease, end at n_entries; keys strictly
+ * ascending): FG_ERR_ARG otherwise. */
 int fg_import_index(fg_ctx* ctx, uint64_t n_keys, const uint64_t* keys, const uint64_t* key_off,
                     uint64_t n_entries, const uint64_t* entries, uint64_t n_repetitive,
                     const uint64_t* repetitive_keys, float sample_rate, int on_device);

@@ -500,5 +500,7 @@ def ref_consensus(pairs, threads=1, binary=None):
                               "--consensus-pairs", path], check=True, capture_output=True, text=True)
     finally:
         os.unlink(path)
+    if os.environ.get("FLYE_REF_STDERR"):
+        sys.stderr.write(out.stderr)
     info = json.loads([l for l in out.stderr.strip().splitlines() if l.startswith("{")][-1])
     return out.stdout, info

@@ -21,7 +21,7 @@ from oracle import oracle as O  # noqa: E402
 # overlaps between consecutive reads of a disjointig: 3-12 kb, raw-read error rates (two reads at 12 % each differ
 # by ~20 %), some with homopolymers, a few with unequal lengths (band doubling)
 SPECS = ([dict(seed=5000 + i, n=3000 + (i * 37) % 9000, err=(0.02, 0.1, 0.2, 0.25)[i % 4], hp=(0, 30)[i % 2]) for i in range(360)]
-         + [dict(seed=6000 + i, n=4000 + 500 * i, err=0.15, shift=40 + 30 * i) for i in range(24)])
+         + [dict(seed=6000 + i, n=4000 + 500 * i, err=0.15, shift=40 + 10 * i) for i in range(24)])
 
 
 def main():

@@ -21,7 +21,7 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/flye_gpu.h but not exported"
     assert set(gpu.ABI_SYMBOLS) <= set(names)
-    assert lib.fg_abi_version() == 3
+    assert lib.fg_abi_version() == 4
     # the batch scheduler above the ABI (include/flye_gpu_bridge.h)
     bridge = _declared("flye_gpu_bridge.h", "fgb_")
     assert len(bridge) >= 8

@@ -200,3 +200,20 @@ def test_two_rank_sharded_build_and_overlaps_on_device(built, tmp_path):
     r = [eval(open(tmp_path / f"gpu_ok{k}").read()) for k in range(2)]
     for preset in ("raw", "hifi"):
         assert r[0][preset][0] != r[1][preset][0] and min(r[0][preset][0][1], r[1][preset][0][1]) > 0   # both built a real piece
+
+
+@pytest.mark.gpu
+def test_device_to_device_collectives_path_one_rank(built):
+    """flye_amd/dist.py with on_device=True (what bench.py --gpus N selects with the nccl backend): RCCL all-reduce
+    of the batch frequencies and the sums, broadcasts into the context's own full-size arrays, on device memory
+    wrapped through __cuda_array_interface__.  RCCL refuses two ranks on one device, so a fresh child process runs
+    ONE rank with every collective forced on (tools/sharded_build_check.py); index and overlaps must equal the
+    ordinary build's."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+                          os.path.join(ROOT, "tools", "sharded_build_check.py")], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("index identical True") == 2 and "False" not in out.stdout

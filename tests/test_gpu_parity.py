@@ -734,3 +734,127 @@ def test_lookup_table_split_into_parts(built, golden_cases, monkeypatch, name):
     res = det2.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
                                    maxOverlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
+
+
+@pytest.mark.parametrize("name", ["raw_pb", "hifi", "corrected_local"])
+def test_index_build_batches_and_slices_are_invisible(built, golden_cases, monkeypatch, name):
+    """The selection runs in batches of reads (FG_INDEX_BATCH_KMERS k-mer positions of scratch) and the
+    sort in slices of key bins (FG_INDEX_SLICE_ENTRIES): forced to dozens of batches and slices at golden-case
+    size, the index must still be the reference's (vertex_index.cpp:25-125, :389-483), bit for bit."""
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    from flye_amd import config
+    cfg = config.preset(case["preset"])
+    monkeypatch.setenv("FG_INDEX_BATCH_KMERS", str(int(rs.total_bases) // 37))
+    monkeypatch.setenv("FG_INDEX_SLICE_ENTRIES", str(max(1000, int(case["index"]["index_entries"]) // 23)))
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    check_index_stats(st, case["index"])
+    assert index_digest(vi.export()) == case["index"]["sha256"]
+    det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
+                                  maxOverlaps=case.get("max_overlaps", 0))
+    assert res.lines() == golden_lines(name)     # the "owns an entry" bits come from the batched selection too
+
+
+def test_solid_selection_in_steps_with_sliced_counters(built, golden_cases):
+    """fg_index_kmer_hist / count_slice / batch_freq / batch_select / selection_done: the counters of a key RANGE
+    only (what one rank of several holds).  Two 'ranks' played one after the other on one context: each counts
+    its own range and writes the frequencies it knows; their sum is the complete array (checked against a
+    whole-range count), the selection from it equals the one-call build's, and a build_range outside the counted
+    range is refused."""
+    import torch
+    from flye_amd import config, dist, gpu
+    case = golden_cases["raw_pb"]
+    rs = golden_reads(case)
+    cfg = config.preset("raw")
+    ctx = gpu.Context(17, 0)
+    ctx.set_reads(rs)
+    vi = gpu.VertexIndex(ctx, 1.0)
+    khist = vi.kmer_hist()
+    assert int(khist.sum()) == int(np.maximum(rs.length.astype(np.int64) - 17, 0).sum())
+    ranges = dist.balanced_bin_ranges(khist, 2)
+    dev = torch.device("cuda", 0)
+    parts, distinct = [], 0
+    for r in range(2):
+        d, nb = vi.count_slice(cfg, *ranges[r])
+        distinct += d
+        assert nb == 1
+        ptr, n = vi.batch_freq(0)
+        parts.append(dist._view(ptr, n, dev, "<i4").clone())
+        if r == 1:
+            with pytest.raises(gpu.FlyeGpuError):       # selection not finished
+                vi.build_range(*ranges[1])
+    assert distinct == int(case["index"]["total_kmers"])
+    assert int(((parts[0] != 0) & (parts[1] != 0)).sum()) == 0      # every k-mer is counted by exactly one range
+    # rank 1's context state is live: complete its array with rank 0's share, select, build ITS range
+    ptr, n = vi.batch_freq(0)
+    dist._view(ptr, n, dev, "<i4").add_(parts[0])
+    vi.batch_select(0)
+    hist = vi.selection_done()
+    with pytest.raises(gpu.FlyeGpuError):               # rank 0's range was not counted here
+        vi.build_range(*ranges[0])
+    vi.build_range(*ranges[1])
+    # the whole build in one call selects the same positions per bin
+    ctx1 = gpu.Context(17, 0)
+    ctx1.set_reads(rs)
+    vi1 = gpu.VertexIndex(ctx1, 1.0)
+    assert np.array_equal(vi1.begin(cfg), hist)
+    assert int(hist.sum()) > 0
+    ctx.close(); ctx1.close()
+
+
+def test_import_rejects_malformed_arrays(built, golden_cases):
+    """fg_import_index / fg_index_gather_end check the CSR on the device before anything reads lists through it."""
+    from flye_amd import config, gpu
+    case = golden_cases["raw_pb"]
+    rs = golden_reads(case)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    ex = vi.export()
+    good = index_digest(ex)
+    for breakit in ("first", "last", "order", "keys"):
+        keys, off = ex.keys.copy(), ex.key_off.copy()
+        if breakit == "first":
+            off[0] = 1
+        elif breakit == "last":
+            off[-1] += 1
+        elif breakit == "order":
+            off[5], off[6] = off[6] + 3, off[5]
+        else:
+            keys[10], keys[11] = keys[11], keys[10]
+        with pytest.raises(gpu.FlyeGpuError) as e:
+            vi.import_index(gpu.IndexExport(keys, off, ex.entries, ex.repetitive), vi.getSampleRate())
+        assert e.value.code == -3
+    vi.import_index(ex, vi.getSampleRate())
+    assert index_digest(vi.export()) == good
+    ctx.close()
+
+
+def test_memory_stats_follow_the_build(built, golden_cases):
+    from flye_amd import config, gpu
+    case = golden_cases["hifi"]
+    rs = golden_reads(case)
+    cfg = config.preset("hifi")
+    now0, _ = gpu.memory_stats(reset_peak=True)
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    now1, peak1 = gpu.memory_stats()
+    assert peak1 >= now1 > now0
+    ctx.close()
+    now2, _ = gpu.memory_stats()
+    assert now2 <= now0       # (contexts of earlier tests may have been collected meanwhile)
+
+
+@pytest.mark.parametrize("mode", ["direct", "hash"])
+def test_kmer_counter_forms_agree(built, golden_cases, monkeypatch, mode):
+    """KmerCounter (vertex_index.cpp:499-616) as a direct-addressed array (large read sets) and as a hashed table
+    sized by the input (small ones): the same index either way."""
+    case = golden_cases["raw_ont_rc"]
+    rs = golden_reads(case)
+    from flye_amd import config
+    monkeypatch.setenv("FG_COUNT_MODE", mode)
+    ctx, vi, st, det = _gpu_setup(rs, config.preset(case["preset"]))
+    check_index_stats(st, case["index"])
+    assert index_digest(vi.export()) == case["index"]["sha256"]
+    kt = ctx.kernel_times()
+    assert "k_count" in kt
+    ctx.close()

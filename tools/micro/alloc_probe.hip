@@ -27,6 +27,31 @@ int main()
 				   round, sz / 1e9, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, sz / 1e9 / (t3 - t2), (t4 - t3) * 1e3);
 			fflush(stdout);
 		}
+	// is it the size of ONE allocation?  64 GiB as 2 x 32, 4 x 16, 8 x 8 GiB held at the same time
+	for (int parts : {2, 4, 8, 1})
+	{
+		void* p[8] = {};
+		const size_t each = (64ULL << 30) / parts;
+		double t0 = now();
+		for (int i = 0; i < parts; ++i) CK(hipMalloc(&p[i], each));
+		double t1 = now();
+		for (int i = 0; i < parts; ++i) CK(hipMemsetAsync(p[i], 0, each, s));
+		CK(hipStreamSynchronize(s)); double t2 = now();
+		for (int i = 0; i < parts; ++i) CK(hipFree(p[i]));
+		double t3 = now();
+		printf("64 GiB as %d x %.0f GiB: malloc %8.2f ms, memset %8.2f ms, free %8.2f ms\n", parts, each / double(1ULL << 30),
+			   (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
+		fflush(stdout);
+	}
+	// one allocation just below / above 64 GiB, and 128 GiB
+	for (size_t sz : {60ULL << 30, (64ULL << 30) - (2ULL << 20), 64ULL << 30, 66ULL << 30, 128ULL << 30})
+	{
+		void* p = nullptr;
+		double t0 = now(); CK(hipMalloc(&p, sz)); double t1 = now();
+		CK(hipFree(p)); double t2 = now();
+		printf("hipMalloc %.3f GiB: malloc %8.2f ms, free %8.2f ms\n", sz / double(1ULL << 30), (t1 - t0) * 1e3, (t2 - t1) * 1e3);
+		fflush(stdout);
+	}
 	// stream-ordered pool with a release threshold: the second allocation of a size comes out of the pool
 	hipMemPool_t pool; CK(hipDeviceGetDefaultMemPool(&pool, 0));
 	unsigned long long thr = ~0ULL; CK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));

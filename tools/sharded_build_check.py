@@ -1,6 +1,7 @@
-"""The device-to-device path of the sharded index build (flye_amd/dist.py, on_device=True: pieces wrapped as
-torch tensors over __cuda_array_interface__, RCCL collectives, fg_import_index from device pointers), on
-however many ranks the launcher gives -- one rank on a one-GPU box exercises every call of that path.
+"""The device-to-device path of the sharded index build (flye_amd/dist.py, on_device=True: the batch frequencies, the
+sums and the CSR pieces as torch tensors over __cuda_array_interface__, RCCL all-reduce / broadcast on them, the
+gather straight into the context's arrays), on however many ranks the launcher gives -- one rank on a one-GPU box
+exercises every call of that path (FLYE_FORCE_COLLECTIVES: the collectives run in a one-rank group too).
     python -m torch.distributed.run --nproc-per-node N tools/sharded_build_check.py"""
 import os
 import sys
@@ -14,6 +15,7 @@ from flye_amd import config, dist, gpu, synth
 from helpers import index_digest
 
 rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+os.environ["FLYE_FORCE_COLLECTIVES"] = "1"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(local)
 td.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
