@@ -61,7 +61,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scale", type=float, default=None, help="genome scale (default = --gpus)")
+    ap.add_argument("--scale", type=float, default=None, help="genome scale (default: --gpus for weak scaling, 1 for strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: the genome (reads, index) grows with --gpus, per-rank queries stay ~fixed; strong: the "
+                         "E. coli workload itself is split over the ranks")
     ap.add_argument("--cpu-sample-bp", type=float, default=250e6)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-reference", action="store_true",
@@ -100,7 +103,7 @@ def main():
 
     from flye_amd import config, dist, gpu, workloads
 
-    scale = args.scale if args.scale is not None else float(world)
+    scale = args.scale if args.scale is not None else (float(world) if args.scaling == "weak" else 1.0)
     t0 = time.time()
     rs, min_ovlp, preset = workloads.ecoli_pb50(seed=12345, scale=scale)
     cfg = config.preset(preset)
@@ -111,12 +114,15 @@ def main():
     ctx.set_reads(rs)
     t_upload = time.time() - t0
     vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    t0 = time.perf_counter()
     if world > 1:
-        # index build sharded by key range over the ranks: sums all-reduce + all-gather of the CSR pieces
-        # (RCCL over xGMI with the nccl backend), every rank then holds the whole index (flye_amd/dist.py)
+        # index build sharded by key range over the ranks: k-mer counters of the rank's own key range, frequency
+        # all-reduce per batch of reads, sums all-reduce, all-gather of the CSR pieces in place (RCCL over xGMI with
+        # the nccl backend), every rank then holds the whole index (flye_amd/dist.py)
         st = dist.build_index_sharded(vi, cfg, rank, world, on_device=(backend == "nccl"))
     else:
         st = vi.build(cfg)
+    t_index_wall = time.perf_counter() - t0
     # --min-ovlp of the pipeline driver (N90 rule) only filters reads by length (main_assemble.cpp:183, done in
     # workloads.ecoli_pb50) and feeds Extender; the DETECTOR always runs with minimumOverlap = 1000
     # (main_assemble.cpp:174 overrides the parameter before the detector is built at :229-238)
@@ -203,17 +209,20 @@ def main():
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this source state (profiles/)"
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"unreadable: {e}"
+        stages = stage_rooflines(serial_ktimes, res.query_bp, m, d, ovl, prof if os.path.exists(prof) and traffic_note.startswith("rocprofv3") else None)
+        dom_stage = max(stages.items(), key=lambda kv: kv[1]["exclusive_ms"])[0] if stages else None
         line = {
             "metric": "Gbp reads overlapped/sec", "value": round(value, 6), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "E.coli PB 50x (synthetic, raw-read cfg): overlap stage, index resident",
                        "genome_bp": int(4_640_000 * scale), "reads": rs.n, "read_bp": rs.total_bases,
                        "queries_per_rank": int(len(queries)), "min_overlap": det_min_ovlp, "min_read_len": min_ovlp,
                        "kmer": int(cfg["kmer_size"]),
-                       "sharding": f"queries: reads by id over {world} rank(s), no data-path collective; index: built sharded by "
-                                   f"key range + all-gather, then resident on every rank"},
+                       "sharding": (f"queries: reads by id over {world} ranks, no data-path collective; index: built sharded by "
+                                    f"key range (counters, sort) + all-gather, then resident on every rank") if world > 1
+                                   else "one rank: all queries, index built and resident on this GPU"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_source": traffic_note,
@@ -225,13 +234,19 @@ def main():
                                         "(FG_CHAIN_STREAMS=1); ms per pass there: " +
                                         ", ".join(f"{k_} {v_[0] * 1e3:.1f}" for k_, v_ in
                                                   sorted(serial_ktimes.items(), key=lambda kv: -kv[1][0])[:6])},
+            # whole stages (all launches of all their kernels against the stage's algorithmic bytes), so that a fraction
+            # cannot be moved by where a stage is cut into kernels; times = exclusive device time of the serialised pass
+            "roofline_stage": (dict(stages[dom_stage], stage=dom_stage, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s") if dom_stage else None),
+            "stages": stages,
             "work": {"seed_hits_per_bp": round(m, 4), "dp_elements_per_bp": round(d, 4),
                      "overlaps": int(len(res.recs)), "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
                      "kernel_ms_per_step": {k: round(v[0] / args.steps * 1e3, 3) for k, v in
                                             sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
                      "kernel_ms_note": "event-bracketed; k_group_prep, k_chain_dp and k_chain_finish run on three streams "
                                        "side by side, so their sums exceed the wall time they occupy",
-                     "index_build_s": round(st["build_seconds"], 3),
+                     "index_build_s": round(st["build_seconds"], 4), "index_build_wall_s": round(t_index_wall, 4),
+                     # build + ONE pass over all queries, reads already uploaded (SURVEY §8d "end-to-end figure")
+                     "end_to_end_gbps": round(total_bp / (t_index_wall + elapsed / args.steps) / 1e9, 4),
                      "index_build_collectives": ({"bytes": int(st["collective_bytes"]), "allgather_s": round(st["allgather_s"], 4),
                                                   "piece_of_rank0": list(st["piece"])} if world > 1 else None),
                      "read_gen_s": round(t_gen, 2),
@@ -262,6 +277,37 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         td.destroy_process_group()
+
+
+STAGES = {
+    # stage -> (kernel name prefixes, algorithmic bytes per bp as a function of m, d, overlaps/bp: SURVEY.md §8d)
+    "seed_collect": (("k_probe", "k_fill", "k_exscan"), lambda m, d, o: 16.25 + 20.0 * m),
+    "hit_sort": (("k_sort",), lambda m, d, o: 24.0 * m),
+    "chain": (("k_group", "k_chain", "k_prim"), lambda m, d, o: 20.0 * d + 44.0 * o),
+}
+
+
+def stage_rooflines(serial_ktimes, bp, m, d, ovl, traffic_file):
+    """Per stage of the pass: algorithmic GB, exclusive device ms (serialised pass), achieved GB/s and fraction of
+    the 8 TB/s HBM roofline; counted traffic (FETCH_SIZE + WRITE_SIZE of every kernel of the stage, profiles/) and
+    its ratio to the algorithmic bytes when the committed counters belong to this source state."""
+    tj = json.load(open(traffic_file)) if traffic_file else {}
+    out = {}
+    for name, (prefixes, per_bp) in STAGES.items():
+        ks = [k for k in serial_ktimes if k.split("<")[0].startswith(prefixes)]
+        sec = sum(serial_ktimes[k][0] for k in ks)
+        if sec <= 0:
+            continue
+        alg = per_bp(m, d, ovl) * bp
+        ent = {"kernels": sorted(ks), "algorithmic_bytes": int(alg), "exclusive_ms": round(sec * 1e3, 3),
+               "achieved": round(alg / sec / 1e9, 2), "frac": round(alg / sec / 1e9 / HBM_PEAK_GBS, 5)}
+        counted = [tj[k]["bytes_per_pass"] for k in tj if k.split("<")[0].startswith(prefixes) and isinstance(tj[k], dict)
+                   and "bytes_per_pass" in tj[k]]
+        if counted:
+            ent["traffic"] = int(sum(counted))
+            ent["traffic_ratio"] = round(sum(counted) / alg, 2)
+        out[name] = ent
+    return out
 
 
 def kernel_source_digest() -> str:

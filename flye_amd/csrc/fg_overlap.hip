@@ -1067,8 +1067,21 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	// The batch is cut into chunks so that the per-chunk scratch (8 B per query k-mer,
 	// ~70 B per seed hit) stays bounded whatever the caller passes; a chunk whose hits
 	// exceed the budget is halved.  E. coli 50x is one chunk.
-	const u64 kmerBudget = getenv("FG_KMER_BUDGET") ? strtoull(getenv("FG_KMER_BUDGET"), nullptr, 10) : (1ULL << 30);
-	const u64 hitBudget = getenv("FG_HIT_BUDGET") ? strtoull(getenv("FG_HIT_BUDGET"), nullptr, 10) : (3ULL << 29);
+	u64 kmerBudget = getenv("FG_KMER_BUDGET") ? strtoull(getenv("FG_KMER_BUDGET"), nullptr, 10) : (1ULL << 30);
+	u64 hitBudget = getenv("FG_HIT_BUDGET") ? strtoull(getenv("FG_HIT_BUDGET"), nullptr, 10) : (3ULL << 29);
+	if (!getenv("FG_KMER_BUDGET") && !getenv("FG_HIT_BUDGET"))
+	{
+		// ... and by what the device has left beside the resident index (a CHM13-sized index leaves ~80 of 288 GB):
+		// the chunk scratch may grow into the free memory plus what it already holds, less a reserve
+		size_t freeB = 0, totalB = 0;
+		HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+		const u64 held = c->dHitKey.bytes() + c->dHitKey32.bytes() + c->dHitVal.bytes() + c->dCur.bytes() + c->dExt.bytes() +
+						 c->dScore.bytes() + c->dBack.bytes() + c->dTmp32.bytes() + c->dCand.bytes() + c->dProbe.bytes();
+		const u64 avail = (u64)freeB + held;
+		const u64 usable = avail > (8ULL << 30) ? (avail - (4ULL << 30)) / 10 * 9 : avail / 2;
+		hitBudget = std::min(hitBudget, std::max<u64>(16ULL << 20, usable / 100 * 85 / 80));	// ~70 B per hit, grow-only slack
+		kmerBudget = std::min(kmerBudget, std::max<u64>(16ULL << 20, usable / 100 * 15 / 9));	// 8 B per query k-mer
+	}
 	std::vector<std::pair<u32, u32>> todo;	// stack of [qa, qb)
 	{
 		std::vector<std::pair<u32, u32>> chunks;

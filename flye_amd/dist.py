@@ -39,6 +39,32 @@ def merge_sharded(per_rank_ids, per_rank_lists):
     return [merged[k] for k in sorted(merged)]
 
 
+# ---- option B of SURVEY.md §8(e): index sharded by TARGET read, seed hits exchanged -----------------------------
+# Not the layout bench.py runs (the replicated index fits 288 GB for every BASELINE config); what is
+# kept here, tested on CPU (tests/test_dist.py), is the part of it that bit parity hangs on: the order in which the
+# query's owner must line the received hits up before the std::sort emulation.
+def owner_of_target(record, world: int):
+    """the rank whose index shard holds the entries of this stored record (forward or reverse strand of read i)"""
+    return (np.asarray(record) >> 1) % world
+
+
+def option_b_receive_order(cur_pos, ext_pos, ext_id, flip_at_cur, ext_len, k: int):
+    """Hits (curPos, extPos, extId) of ONE query gathered from the index shards in arbitrary order -> the
+    permutation that restores the reference's emission order, i.e. the input order of its unstable hit sort
+    (overlap.cpp:176-204): ascending curPos, and per query k-mer ascending STORED global position
+    (vertex_index.cpp:108-114).  The stored (record, position) of a hit is recovered from what was reported:
+    a flipped query k-mer reports (record ^ 1, len - pos - k) (vertex_index.h:158-174), and whether the k-mer at
+    curPos was flipped is known to the receiver (``flip_at_cur[curPos]``); ``ext_len[i]`` = length of hit i's
+    target.  (curPos, stored record, stored position) is a total order: no two hits of a query share it."""
+    cur_pos = np.asarray(cur_pos, np.int64)
+    ext_pos = np.asarray(ext_pos, np.int64)
+    ext_id = np.asarray(ext_id, np.int64)
+    fl = np.asarray(flip_at_cur, bool)[cur_pos]
+    rec = np.where(fl, ext_id ^ 1, ext_id)
+    pos = np.where(fl, np.asarray(ext_len, np.int64) - ext_pos - k, ext_pos)
+    return np.lexsort((pos, rec, cur_pos))
+
+
 # ---- sharded index build ------------------------------------------------------------------------------
 def balanced_bin_ranges(hist, world: int):
     """``world`` contiguous bin ranges [lo, hi) covering all bins, each holding about 1/world of the accepted

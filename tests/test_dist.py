@@ -131,6 +131,111 @@ def test_sharded_index_pieces_allgather_gloo(built, tmp_path, world):
     assert all(int(open(tmp_path / f"ok{r}").read()) > 1000 for r in range(world))
 
 
+# ---- option B (index sharded by target read + seed-hit exchange): the receiver's order ---------------------------
+def _kmers_with_flip(rs, r, k):
+    """forward k-mers of read r at positions 0 .. len-k-1 (kmer.h:193-198): canonical value and whether it was flipped"""
+    L = int(rs.length[r])
+    w = rs.words[int(rs.word_off[r]):int(rs.word_off[r + 1])]
+    sh = np.arange(32, dtype=np.uint64) * np.uint64(2)
+    b = ((w[:, None] >> sh[None, :]) & np.uint64(3)).reshape(-1)[:L].astype(np.uint64)
+    n = L - k
+    if n <= 0:
+        return np.empty(0, np.uint64), np.empty(0, bool)
+    fw = np.zeros(n, np.uint64)
+    rv = np.zeros(n, np.uint64)
+    for t in range(k):
+        fw = (fw << np.uint64(2)) | b[t:t + n]
+        rv = rv | ((np.uint64(3) - b[t:t + n]) << np.uint64(2 * t))
+    return np.minimum(fw, rv), rv < fw
+
+
+def _emit_hits(ex, rs, r, k, keep=None):
+    """Seed hits of forward read r against the exported index `ex` in the reference's emission order
+    (overlap.cpp:176-196 + vertex_index.h:158-174); `keep(record)` restricts the index to a shard's entries."""
+    canon, flip = _kmers_with_flip(rs, r, k)
+    rep = set(ex.repetitive.tolist())
+    cur, ext, eid = [], [], []
+    idx = np.searchsorted(ex.keys, canon)
+    for p in range(len(canon)):
+        i = int(idx[p])
+        if int(canon[p]) in rep or i >= len(ex.keys) or ex.keys[i] != canon[p]:
+            continue
+        for e in ex.entries[int(ex.key_off[i]):int(ex.key_off[i + 1])].tolist():
+            rec, pos = e >> 32, e & 0xFFFFFFFF
+            if keep is not None and not keep(rec):
+                continue
+            if flip[p]:
+                pos = int(rs.length[rec >> 1]) - pos - k
+                rec ^= 1
+            if rec == 2 * r and pos == p:
+                continue                    # the trivial match (overlap.cpp:188-190)
+            cur.append(p); ext.append(pos); eid.append(rec)
+    return np.array(cur, np.int64), np.array(ext, np.int64), np.array(eid, np.int64), flip
+
+
+def _option_b_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as td
+    from flye_amd import config, dist, synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    k = 17
+    rs = synth.simulate(seed=5, genome_len=12_000, coverage=14, kind="hifi", n_repeat_families=3, n_tandems=8,
+                        n_homopolymers=8).filter_min_len(1000)
+    cfg = config.preset("corrected")
+    o = O.Oracle(k, threads=1)
+    o.set_reads(rs)
+    o.build_index(cfg)
+    full = o.export_index()
+    # this rank's index shard = the entries whose TARGET read it owns; it probes ALL queries against it and sends
+    # each query's hits to the query's owner (read i -> rank i % world), in an arbitrary order
+    rng = np.random.default_rng(100 + rank)
+    outbox = [dict() for _ in range(world)]
+    for r in range(rs.n):
+        cur, ext, eid, _ = _emit_hits(full, rs, r, k, keep=lambda rec: dist.owner_of_target(rec, world) == rank)
+        perm = rng.permutation(len(cur))
+        outbox[int(dist.owner_of(r, world))][r] = (cur[perm], ext[perm], eid[perm])
+    inbox = [None] * world
+    td.all_gather_object(inbox, outbox)                      # the all-to-all, as objects
+    checked = ties = moved = 0
+    for r in range(rank, rs.n, world):
+        parts = [inbox[g][rank][r] for g in range(world)]
+        cur = np.concatenate([p[0] for p in parts]); ext = np.concatenate([p[1] for p in parts])
+        eid = np.concatenate([p[2] for p in parts])
+        want_cur, want_ext, want_eid, flip = _emit_hits(full, rs, r, k)
+        order = dist.option_b_receive_order(cur, ext, eid, flip, rs.length[(eid >> 1)], k)
+        cur, ext, eid = cur[order], ext[order], eid[order]
+        assert np.array_equal(cur, want_cur) and np.array_equal(ext, want_ext) and np.array_equal(eid, want_eid)
+        # the unstable hit sort (overlap.cpp:201-204) then runs on identical input: identical permutation
+        keys = (eid.astype(np.uint64) << np.uint64(32)) | cur.astype(np.uint64)
+        sp = O.std_sort_perm(keys)
+        assert np.array_equal(ext[sp], want_ext[O.std_sort_perm((want_eid.astype(np.uint64) << np.uint64(32)) | want_cur.astype(np.uint64))])
+        # ... which an arrival-order input would not give wherever keys tie
+        arrival = np.concatenate([p[1] for p in parts])
+        akeys = np.concatenate([(p[2].astype(np.uint64) << np.uint64(32)) | p[0].astype(np.uint64) for p in parts])
+        moved += int(not np.array_equal(arrival[O.std_sort_perm(akeys)], ext[sp]))
+        ties += int(len(keys) - len(np.unique(keys)))
+        checked += len(keys)
+    open(os.path.join(out_dir, f"b_ok{rank}"), "w").write(repr((checked, ties, moved)))
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_option_b_receiver_restores_emission_order_gloo(built, tmp_path, world):
+    """SURVEY.md §8(e) option B: index sharded by target read, every rank probes all queries against its shard,
+    hits travel to the query's owner, which re-orders them by (curPos, stored record, stored position) before the
+    std::sort emulation.  Here with the oracle's index and numpy seed collection standing in for the device."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_option_b_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [eval(open(tmp_path / f"b_ok{r}").read()) for r in range(world)]
+    assert sum(x[0] for x in res) > 5000        # hits checked
+    assert sum(x[1] for x in res) > 0           # the case has tied (extId, curPos) keys ...
+    assert sum(x[2] for x in res) > 0           # ... and arrival order would have changed the sorted result
+
+
 def test_balanced_bin_ranges():
     from flye_amd import dist
     rng = np.random.default_rng(0)

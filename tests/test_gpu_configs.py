@@ -27,10 +27,11 @@ def _properties(res, det_min, n_reads):
     assert int(res.query_off[-1]) == len(rr) and np.all(np.diff(res.query_off.astype(np.int64)) >= 0)
 
 
-def _sampled_oracle_check(rs, cfg, vi, det, res, queries, sample_pos, k):
+def _sampled_oracle_check(rs, cfg, vi, det, res, queries, sample_pos, k, ex=None):
     """records of queries[sample_pos] in `res` against the oracle on the touched part of the index"""
     from oracle import oracle as O
-    ex = vi.export()
+    if ex is None:
+        ex = vi.export()
     reads = (queries[sample_pos] // 2).astype(np.int64)
     sub = sub_index(ex, rs, reads, k)
     del ex
@@ -105,33 +106,118 @@ def test_config4_synthetic_10gb_rank0_of_8(built):
           f"{n} sampled records identical to the oracle")
 
 
-def test_config5_hifi_parameters_at_scale(built):
-    """configs[4] parameters (asm_hifi.cfg: minimizer index w = 10, base-level divergence on homopolymer-
-    compressed sequence, --hifi-error gate) on the largest HiFi read set that keeps the suite short:
-    100 Mb genome, 30x, 3 Gbp.  (CHM13 itself is 93 Gbp: the residency table is in DESIGN.md §6.)"""
-    from flye_amd import config, gpu, workloads
+def test_config5_hifi_proxy_rank0_of_8_bounded_memory(built):
+    """configs[4] "Human CHM13 HiFi 30x, 8 x MI355X" on the survey's proxy (310 Mb genome, 30x,
+    9.3 Gbp of HiFi reads, asm_hifi.cfg: minimizer index w = 10, base-level divergence on homopolymer-compressed
+    sequence).  The gate: the synthetic reads carry 0.3 % error EACH, so true overlaps diverge by ~0.6 %; the
+    --hifi-error 0.003 gate of the real data set would reject them all, the test's gate is 0.01.
+
+    What one rank of eight does, on one GPU: the batched selection over all reads, ITS key range sorted and
+    run-length encoded, finish with the sums over all ranks -> its piece; the gather of the eight pieces straight
+    into the context's own arrays; then its share of the queries (i % 8 == 0) against the full index.
+    Checked: (1) the device memory the library holds never exceeds a stated bound during the rank's build;
+    (2) the piece equals the same key range of the index built the one-GPU way; (3) the gathered index equals
+    that index; (4) >= 100 sampled query reads against the CPU oracle, record for record."""
+    import torch
+    from flye_amd import config, dist, gpu, workloads
+    W = 8
     t0 = time.time()
-    rs, min_ovlp, preset = workloads.hifi30(genome_len=100_000_000)
+    rs, min_ovlp, preset = workloads.hifi30(genome_len=310_000_000)
     cfg = config.preset(preset)
     k = int(cfg["kmer_size"])
+    assert rs.total_bases > 9e9
+    t_gen = time.time() - t0
+
+    # ---- the index the one-GPU way (in 8 key-range steps), kept on the host as the yardstick
     ctx = gpu.Context(k, 0)
     ctx.set_reads(rs)
     vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
-    st = vi.build(cfg)
+    hist = vi.begin(cfg)
+    ranges = dist.balanced_bin_ranges(hist, W)
+    sums = np.zeros(2, np.uint64)
+    for r in range(W):
+        sums = vi.build_range(*ranges[r])       # running totals of this context
+    st_full = vi.finish(None)
+    full = vi.export()
+    ctx.close()
+    del vi, ctx
+    t_full = time.time() - t0 - t_gen
+    assert st_full["index_entries"] > 1.4e9
+    key_lo = [np.uint64(lo) << np.uint64(2 * k - 12) for lo, hi in ranges]
+    cut = np.searchsorted(full.keys, np.array(key_lo, np.uint64)).tolist() + [len(full.keys)]
+    rcut = np.searchsorted(full.repetitive, np.array(key_lo, np.uint64)).tolist() + [len(full.repetitive)]
+
+    # ---- rank 0 of 8
+    ctx = gpu.Context(k, 0)
+    ctx.set_reads(rs)
+    reads_bytes, _ = gpu.memory_stats(reset_peak=True)
+    vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+    hist0 = vi.begin(cfg)
+    assert np.array_equal(hist0, hist)
+    vi.build_range(*ranges[0])
+    st = vi.finish(sums)
+    _, peak = gpu.memory_stats()
+    e0 = int(hist[ranges[0][0]:ranges[0][1]].sum())
+    total_kmers = int(np.maximum(rs.length.astype(np.int64) - k, 0).sum())
+    batch = 256 << 20
+    # reads + one bit per k-mer position + the larger of {batch scratch: 8 B hash + 1 B flag per position,
+    # this rank's sort: 4 arrays of 8 B + 8 B of run-length scratch per entry} + the piece + 1 GB of slack
+    bound = reads_bytes + total_kmers // 8 + max(9 * batch, 40 * e0) + 20 * e0 + (1 << 30)
+    assert peak <= bound, (peak, bound)
+    piece = vi.export()
+    assert np.array_equal(piece.keys, full.keys[cut[0]:cut[1]])
+    a, b = int(full.key_off[cut[0]]), int(full.key_off[cut[1]])
+    assert np.array_equal(piece.key_off, full.key_off[cut[0]:cut[1] + 1] - np.uint64(a))
+    assert np.array_equal(piece.entries, full.entries[a:b])
+    assert np.array_equal(piece.repetitive, full.repetitive[rcut[0]:rcut[1]])
+    assert st["repetitive_frequency"] == st_full["repetitive_frequency"]
+
+    # ---- the gather, straight into the context's arrays: the own piece device to device, the other seven ranks'
+    # pieces (here cut from the yardstick) where their broadcasts would land
+    K, E, R = len(full.keys), len(full.entries), len(full.repetitive)
+    fp, pp, psz = vi.gather_begin(K, E, R)
+    dev = torch.device("cuda", 0)
+    keys, off, ent, rep = (dist._view(fp[0], K, dev), dist._view(fp[1], K + 1, dev), dist._view(fp[2], E, dev),
+                           dist._view(fp[3], R, dev))
+    keys[:cut[1]] = dist._view(pp[0], psz[0], dev)
+    off[:cut[1]] = dist._view(pp[1], psz[0] + 1, dev)[:psz[0]]
+    ent[:b] = dist._view(pp[2], psz[1], dev)
+    rep[:rcut[1]] = dist._view(pp[3], psz[2], dev)
+    keys[cut[1]:] = torch.from_numpy(full.keys[cut[1]:].view(np.int64))
+    off[cut[1]:] = torch.from_numpy(full.key_off[cut[1]:].view(np.int64))
+    ent[b:] = torch.from_numpy(full.entries[b:].view(np.int64))
+    rep[rcut[1]:] = torch.from_numpy(full.repetitive[rcut[1]:].view(np.int64))
+    torch.cuda.synchronize()
+    del keys, off, ent, rep
+    sample_rate = float(np.float32(rs.total_bases) / np.float32(E))
+    vi.gather_end(sample_rate)
+    vi.stats = dict(st, selected_kmers=K, index_entries=E, repetitive_kmers=R, sample_rate=float(np.float32(sample_rate)))
+    assert np.float32(sample_rate).tobytes() == np.float32(st_full["sample_rate"]).tobytes()
+    got = vi.export()
+    assert all(np.array_equal(x, y) for x, y in ((got.keys, full.keys), (got.key_off, full.key_off),
+                                                 (got.entries, full.entries), (got.repetitive, full.repetitive)))
+    del got, piece
+    index_bytes, _ = gpu.memory_stats()
+    t_rank = time.time() - t0 - t_gen - t_full
+
+    # ---- rank 0's share of the overlap stage
     det = gpu.OverlapDetector.for_assemble(ctx, vi, cfg)
     assert det.p.nucl_alignment and det.p.use_hpc
-    # the synthetic reads carry 0.3 % error each (0.6 % pairwise): the gate sits where true overlaps pass
     det.p.max_divergence = 0.01
-    q = np.arange(0, 2 * rs.n, 2, dtype=np.uint32)
+    q = dist.shard_queries(rs.n, 0, W)
     t1 = time.time()
     res = det.getSeqOverlapsBatch(q)
     t2 = time.time()
-    assert rs.total_bases > 2.5e9
     _properties(res, config.DETECTOR_MIN_OVERLAP, rs.n)
     assert np.all(res.recs["seq_divergence"] < 0.01) and np.all(res.recs["edit_distance"] >= 0)
+    bp = int(rs.length[(q // 2).astype(np.int64)].sum())
     rng = np.random.default_rng(6)
-    sample = np.sort(rng.choice(len(q), size=100, replace=False))
-    n = _sampled_oracle_check(rs, cfg, vi, det, res, q, sample, k)
+    sample = np.sort(rng.choice(len(q), size=120, replace=False))
+    n = _sampled_oracle_check(rs, cfg, vi, det, res, q, sample, k, ex=full)
+    _, peak_all = gpu.memory_stats()
     ctx.close()
-    print(f"hifi 100 Mb: {rs.n} reads {rs.total_bases / 1e9:.2f} Gbp, setup {t1 - t0:.0f} s, pass {t2 - t1:.1f} s, "
-          f"{len(res.recs)} overlaps, {n} sampled records identical to the oracle")
+    print(f"hifi proxy 310 Mb, rank 0/8: {rs.n} reads {rs.total_bases / 1e9:.2f} Gbp (gen {t_gen:.0f} s), one-GPU build + export "
+          f"{t_full:.0f} s, rank build + gather {t_rank:.0f} s; reads {reads_bytes / 1e9:.2f} GB, rank-0 entries {e0 / 1e6:.0f} M of "
+          f"{E / 1e6:.0f} M, build peak {peak / 1e9:.2f} GB (bound {bound / 1e9:.2f}), reads + full index {index_bytes / 1e9:.2f} GB, "
+          f"peak incl. overlap scratch {peak_all / 1e9:.2f} GB; {len(q)} queries {bp / 1e9:.2f} Gbp in {t2 - t1:.1f} s "
+          f"({bp / (t2 - t1) / 1e9:.2f} Gbp/s), {len(res.recs)} overlaps, {n} sampled records identical to the oracle")
