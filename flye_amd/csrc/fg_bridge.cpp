@@ -88,6 +88,18 @@ struct SpecClass {
 	std::deque<uint32_t> neighbours;	// forward ids named by results handed out, not computed yet
 	std::unordered_map<uint32_t, uint8_t> seen;	// ids ever computed or queued in this class (bounds repeated work)
 	bool wanted = false;				// low-water mark reached: compute more without waiting for a miss
+	// Bulk mode.  A caller that keeps asking for records of the indexed container in an order nobody can guess
+	// (Extender::assembleDisjointigs starts from the reads in HASH order, extender.cpp:376-381, and walks the overlap
+	// graph from there; ChimeraDetector::estimateGlobalCoverage samples ~1000 reads with rand(), chimera.cpp:55-104)
+	// pays one small device call -- milliseconds -- per request, while ALL forward reads of the container cost the
+	// device tens of milliseconds.  After `bulkTrigger` requests in a class the dispatcher therefore computes every
+	// forward record of the container for that class, `bulkBatch` per call, and keeps the results until they are
+	// asked for (at most `bulkMaxRecs` overlaps waiting).
+	uint64_t requests = 0;
+	bool bulk = false;
+	uint32_t bulkNext = 0;				// next forward read (index) the bulk pass looks at
+	std::vector<uint8_t> done;			// per forward read: a result of this class exists (stored or handed out)
+	uint64_t readyRecs = 0;				// overlaps in `ready`
 };
 
 } // namespace
@@ -121,6 +133,8 @@ struct fgb_container {
 	std::deque<QuickReq*> quickQ;
 	std::map<std::pair<int32_t, uint8_t>, SpecClass> spec;
 	uint32_t maxAhead = 4096;			// FGB_READ_AHEAD (0 switches the read-ahead off)
+	uint32_t bulkTrigger = 64, bulkBatch = 4096;	// FGB_BULK_TRIGGER (0 = never), FGB_BULK_BATCH
+	uint64_t bulkMaxRecs = 64ULL << 20;				// FGB_BULK_MAX_RECS
 	std::vector<float> divStats;
 	fgb_stats stats{0, 0, 0, 0, 0, 0, 0};
 	bool stop = false;
@@ -291,6 +305,25 @@ void fgb_container::run()
 					sc.wanted = false;
 					const uint32_t base = qNFwd ? qFirstId : firstId, cnt = qNFwd ? qNFwd : nFwd;
 					std::vector<uint32_t>& ids = aheadIds[kv.first];
+					if (sc.bulk)
+					{
+						// every forward record not computed yet, bulkBatch per call, while the store has room
+						uint32_t added = 0;
+						if (sc.done.size() < cnt) sc.done.resize(cnt, 0);
+						while (sc.readyRecs < bulkMaxRecs && added < bulkBatch && sc.bulkNext < cnt)
+						{
+							const uint32_t idx = sc.bulkNext++;
+							const uint32_t id = base + 2u * idx;
+							if (sc.done[idx] || sc.ready.find(id) != sc.ready.end()) continue;
+							bool asked = false;
+							for (QuickReq* r : kv.second) asked |= r->id == id;
+							if (asked) continue;
+							ids.push_back(id); ++added;
+						}
+						nbStart[kv.first] = ids.size();
+						if (sc.bulkNext < cnt && sc.readyRecs < bulkMaxRecs) sc.wanted = true;	// the next batch follows at once
+						continue;
+					}
 					for (int strand = 0; strand < 2; ++strand)
 					{
 						uint32_t top = 0; bool any = false;
@@ -397,13 +430,16 @@ void fgb_container::run()
 					const size_t nb0 = nbStart.count(kv.first) ? nbStart[kv.first] : ids.size();
 					for (size_t i = 0; i < kv.second.size(); ++i)
 					{
+						sc.readyRecs += kv.second[i]->recs.size();
+						if (sc.bulk && !(ids[i] & 1u) && ids[i] >= firstId && (ids[i] - firstId) / 2 < sc.done.size()) sc.done[(ids[i] - firstId) / 2] = 1;
 						sc.ready[ids[i]] = SpecEntry{std::move(kv.second[i]), (uint8_t)(i >= nb0 ? 1 : 0)};
 						sc.order.push_back(ids[i]);
 						sc.seen[ids[i]] = 1;
 					}
-					while (sc.ready.size() > 2 * (size_t)maxAhead && !sc.order.empty())
+					while (!sc.bulk && sc.ready.size() > 2 * (size_t)maxAhead && !sc.order.empty())
 					{
-						sc.ready.erase(sc.order.front());		// oldest first; ids already picked up are no-ops
+						auto old = sc.ready.find(sc.order.front());		// oldest first; ids already picked up are no-ops
+						if (old != sc.ready.end()) { sc.readyRecs -= old->second.res->recs.size(); sc.ready.erase(old); }
 						sc.order.pop_front();
 					}
 					while (sc.order.size() > 4 * (size_t)maxAhead) sc.order.pop_front();
@@ -418,7 +454,7 @@ void fgb_container::run()
 					{
 						if (r->status != FG_OK || !r->res) continue;
 						sc.seen[r->id] = 1;
-						queueNeighbours(sc, r->res->recs);
+						if (!sc.bulk) queueNeighbours(sc, r->res->recs);
 					}
 					if (sc.seen.size() > 64 * (size_t)maxAhead + 4 * (size_t)(qNFwd ? qNFwd : nFwd)) sc.seen.clear();
 				}
@@ -440,6 +476,11 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 	if (c->stop) return FG_ERR_STATE;
 	if (!r.words && c->maxAhead)
 	{
+		if (c->bulkTrigger && c->inIndexed(r.id) && !c->qNFwd)
+		{
+			SpecClass& cls = c->spec[std::make_pair(r.maxOverlaps, r.forceLocal)];
+			if (++cls.requests >= c->bulkTrigger && !cls.bulk) { cls.bulk = true; cls.wanted = true; c->cvWork.notify_one(); }
+		}
 		auto sit = c->spec.find(std::make_pair(r.maxOverlaps, r.forceLocal));
 		if (sit != c->spec.end())
 		{
@@ -447,13 +488,17 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 			auto it = sc.ready.find(r.id);
 			if (it != sc.ready.end())
 			{
+				sc.readyRecs -= it->second.res->recs.size();
 				r.res = std::move(it->second.res);
 				if (it->second.origin) ++sc.hitsNbSince; else ++sc.hitsSince;
 				sc.ready.erase(it);
 				++c->stats.ahead_hits;
 				c->divStats.insert(c->divStats.end(), r.res->stats.begin(), r.res->stats.end());
-				if (r.maxOverlaps == 0 && !r.forceLocal) c->queueNeighbours(sc, r.res->recs);	// what the caller asks for next
+				if (r.maxOverlaps == 0 && !r.forceLocal && !sc.bulk) c->queueNeighbours(sc, r.res->recs);	// what the caller asks for next
 				// keep the device ahead of the callers: top up when half of the last call's results are gone
+				// (bulk mode: when the store has room again)
+				if (sc.bulk) { if (!sc.wanted && sc.bulkNext < c->nFwd && sc.readyRecs < c->bulkMaxRecs) { sc.wanted = true; c->cvWork.notify_one(); } }
+				else
 				if (!sc.wanted && sc.ready.size() * 2 < sc.ahead) { sc.wanted = true; c->cvWork.notify_one(); }
 				r.done = true; r.status = FG_OK;
 				return FG_OK;
@@ -479,6 +524,9 @@ int fgb_create(fgb_container** out, fg_ctx* ctx, const struct fg_detector_params
 		c->maxBatch = max_batch ? max_batch : 4096;
 		c->lingerUs = linger_us;
 		if (getenv("FGB_READ_AHEAD")) c->maxAhead = (uint32_t)std::max(0, atoi(getenv("FGB_READ_AHEAD")));
+		if (getenv("FGB_BULK_TRIGGER")) c->bulkTrigger = (uint32_t)std::max(0, atoi(getenv("FGB_BULK_TRIGGER")));
+		if (getenv("FGB_BULK_BATCH")) c->bulkBatch = (uint32_t)std::max(1, atoi(getenv("FGB_BULK_BATCH")));
+		if (getenv("FGB_BULK_MAX_RECS")) c->bulkMaxRecs = strtoull(getenv("FGB_BULK_MAX_RECS"), nullptr, 10);
 		const int rc = fg_container_info(ctx, &c->firstId, &c->nFwd, &c->qFirstId, &c->qNFwd);
 		if (rc != FG_OK) return rc;
 		fgb_container* raw = c.release();

@@ -327,6 +327,9 @@ struct fg_ctx {
 	DevBuf<u32> dQuery;			// query record indices
 	DevBuf<u64> dQKmerOff;		// per query prefix of k-mer counts
 	DevBuf<u64> dProbe;			// per query k-mer: table value (0 = miss)
+	// probes partitioned by table region (tables beyond the caches): (region | k-mer, position) pairs, twice, + sort scratch
+	DevBuf<u64> dPartK0, dPartV0, dPartK1, dPartV1;
+	DevBuf<char> dPartScratch;
 	DevBuf<u64> dHitOff;		// per query hit offsets (nq+1)
 	DevBuf<u64> dFiltOff;		// per query repetitive-position offsets (nq+1)
 	DevBuf<i32> dFiltPos;

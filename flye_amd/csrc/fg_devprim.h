@@ -123,6 +123,8 @@ constexpr u64 RS_MAX_N = (1ULL << 30) - 1;		// a status word carries a 30-bit ru
 
 #if defined(__HIPCC__)
 
+namespace {		// kernels of a header shared by several translation units: one internal copy each
+
 // digit counts of every pass in one sweep over the keys: hist[pass * 256 + digit]
 __global__ void __launch_bounds__(RS_THREADS) k_rs_hist(const u64* __restrict__ keys, u64 n, int beginBit, int nPasses,
 														 unsigned long long* __restrict__ hist)
@@ -264,6 +266,8 @@ k_rs_onesweep(const u64* __restrict__ keysIn, const u64* __restrict__ valsIn, u6
 		}
 	}
 }
+
+} // namespace
 
 #endif // __HIPCC__
 

@@ -22,6 +22,7 @@
 // (ascending curPos, per k-mer ascending stored position).
 #include "fg_ctx.h"
 #include "fg_wavesort.h"
+#include "fg_devprim.h"
 #include <atomic>
 
 #include <algorithm>
@@ -141,6 +142,90 @@ __global__ void k_probe(const u32* __restrict__ query, const u64* __restrict__ w
 		pr[p] = v;
 	}
 	// block sums
+	for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o); filt += __shfl_down(filt, o); }
+	if ((threadIdx.x & 63) == 0) { shA[threadIdx.x >> 6] = hits; shB[threadIdx.x >> 6] = filt; }
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		u64 h = 0, f = 0;
+		for (int i = 0; i < WG / 64; ++i) { h += shA[i]; f += shB[i]; }
+		hitCnt[q] = h; filtCnt[q] = f;
+	}
+}
+
+// ---- seed collection against a lookup table beyond the caches: probes partitioned by table region ----------------
+// A table of tens of GB (D. melanogaster: 18 GB, 10 Gbp of reads: 46 GB) serves random 64-byte probes at a tenth of
+// the rate of one that sits in the Infinity Cache (4 against 40 G probes/s: every probe is a TLB miss and a DRAM
+// page of its own).  So the probes of a batch of queries are first ordered by the table region they fall into:
+//   k_probe_emit    per query k-mer: (region << 34 | canonical k-mer, position | flags)
+//   one pass of the onesweep radix sort (fg_devprim.h) on the region bits -- a stable partition into 256 regions
+//   k_probe_sorted  probes region by region (a region = 1/256 of the table: inside the Infinity Cache and the TLB
+//                   reach while it is worked on); a hit scatters its value to the position's slot of `probe`
+//                   (misses -- four in five -- write nothing: the array starts zeroed)
+//   k_probe_count   the per-query totals k_probe gives, from the array
+// Narrow tables only (k <= 17: the k-mer leaves room for the region in one 64-bit key).
+#define PROBE_REGION_BITS 8
+#define PART_KEY_BITS 34
+__global__ void k_probe_emit(u32 q0, const u32* __restrict__ query, const u64* __restrict__ words,
+							 const u64* __restrict__ wordOff, const i32* __restrict__ len,
+							 const u64* __restrict__ kmerOff, const u64* __restrict__ qKmerOff, int k, FgTable table,
+							 int regionShift, const u32* __restrict__ indexedBits, u64* __restrict__ keys, u64* __restrict__ vals)
+{
+	const u32 q = q0 + blockIdx.x;
+	const u32 rec = query[q];
+	const u32 r = rec >> 1;
+	const bool rc = rec & 1;
+	const i32 nk = len[r] - k;
+	const u64* w = words + wordOff[r];
+	const u64 out0 = qKmerOff[q] - qKmerOff[q0];
+	const u64 kbase = indexedBits ? kmerOff[r] : 0;
+	for (i32 p = threadIdx.x; p < nk; p += WG)
+	{
+		const i32 qf = rc ? nk - p : p;
+		u64 a, b;
+		fg_kmer_pair(w, qf, k, a, b);
+		const u64 fw = rc ? b : a, rv = rc ? a : b;
+		const bool flip = rv < fw;
+		const u64 key = flip ? rv : fw;
+		const u64 bit = kbase + (u64)qf;
+		const u32 self = (indexedBits && qf < nk) ? ((indexedBits[bit >> 5] >> (bit & 31)) & 1u) : 0u;
+		u32 part = 0;
+		if (table.nParts > 1)
+			while (part + 1 < table.nParts && key >= table.bound[part + 1]) ++part;
+		const u32 g = __umulhi((u32)(fg_mix(key) >> 32), table.groups[part]);
+		const u64 region = (table.slotBase[part] + (u64)g * 8u) >> regionShift;
+		keys[out0 + p] = (region << PART_KEY_BITS) | key;
+		vals[out0 + p] = (qKmerOff[q] + (u64)p) | (self ? FLAG_SELF : 0ULL) | (flip ? FLAG_FLIP : 0ULL);
+	}
+}
+
+__global__ void k_probe_sorted(const u64* __restrict__ keys, const u64* __restrict__ vals, u64 n, FgTable table,
+							   u64* __restrict__ probe)
+{
+	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
+	if (i >= n) return;
+	u64 v = fg_probe<false>(table, keys[i] & ((1ULL << PART_KEY_BITS) - 1));
+	if (v == 0) return;
+	const u64 val = vals[i];
+	if ((u32)(v & FG_CNT_MASK) != FG_CNT_REPETITIVE) v |= val & (FLAG_SELF | FLAG_FLIP);
+	probe[val & ~(FLAG_SELF | FLAG_FLIP)] = v;
+}
+
+__global__ void k_probe_count(const u64* __restrict__ qKmerOff, const u64* __restrict__ probe,
+							  u64* __restrict__ hitCnt, u64* __restrict__ filtCnt)
+{
+	__shared__ u32 shA[WG / 64], shB[WG / 64];
+	const u32 q = blockIdx.x;
+	const u64 a = qKmerOff[q], b = qKmerOff[q + 1];
+	u32 hits = 0, filt = 0;
+	for (u64 i = a + threadIdx.x; i < b; i += WG)
+	{
+		const u64 v = probe[i];
+		if (v == 0) continue;
+		const u32 cnt = (u32)(v & FG_CNT_MASK);
+		if (cnt == FG_CNT_REPETITIVE) ++filt;
+		else hits += cnt - ((v & FLAG_SELF) ? 1u : 0u);
+	}
 	for (int o = 32; o > 0; o >>= 1) { hits += __shfl_down(hits, o); filt += __shfl_down(filt, o); }
 	if ((threadIdx.x & 63) == 0) { shA[threadIdx.x >> 6] = hits; shB[threadIdx.x >> 6] = filt; }
 	__syncthreads();
@@ -846,6 +931,43 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 	HIP_CHECK(hipStreamSynchronize(s));
 }
 
+// seed collection's probe step with the probes partitioned by table region (see k_probe_emit): fills c->dProbe,
+// c->dCntA (hits per query), c->dCntB (repetitive positions per query) like k_probe
+static void probePartitioned(fg_ctx* c, u32 nq, const u64* localOff, const u64* qWords, const u64* qWordOff, const i32* qLen)
+{
+	hipStream_t s = c->stream;
+	const u64 totalQK = localOff[nq];
+	HIP_CHECK(hipMemsetAsync(c->dProbe.p, 0, totalQK * 8, s));
+	int regionShift = 0;
+	while ((c->tableSlots >> regionShift) > (1ULL << PROBE_REGION_BITS)) ++regionShift;
+	const u64 subBudget = getenv("FG_PROBE_SUB_KMERS") ? std::max<u64>(1, strtoull(getenv("FG_PROBE_SUB_KMERS"), nullptr, 10)) : (256ULL << 20);
+	u32 q0 = 0;
+	while (q0 < nq)
+	{
+		u32 q1 = q0 + 1;
+		while (q1 < nq && localOff[q1 + 1] - localOff[q0] <= subBudget) ++q1;
+		const u64 n = localOff[q1] - localOff[q0];
+		if (n)
+		{
+			c->dPartK0.reserve(n); c->dPartV0.reserve(n); c->dPartK1.reserve(n); c->dPartV1.reserve(n);
+			c->dPartScratch.reserve(fgprim::radixSortScratchBytes(n));
+			{ ScopedK t(c->timer, "k_probe_emit");
+			  hipLaunchKernelGGL(k_probe_emit, q1 - q0, WG, 0, s, q0, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p, c->dQKmerOff.p,
+								 c->k, c->table, regionShift, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p, c->dPartK0.p, c->dPartV0.p); }
+			int which;
+			{ ScopedK t(c->timer, "k_probe_partition");
+			  which = fgprim::radixSortPairs(s, c->dPartK0.p, c->dPartV0.p, c->dPartK1.p, c->dPartV1.p, n, PART_KEY_BITS,
+											 PART_KEY_BITS + PROBE_REGION_BITS, c->dPartScratch.p); }
+			{ ScopedK t(c->timer, "k_probe");
+			  hipLaunchKernelGGL(k_probe_sorted, (unsigned)((n + WG - 1) / WG), WG, 0, s, which ? c->dPartK1.p : c->dPartK0.p,
+								 which ? c->dPartV1.p : c->dPartV0.p, n, c->table, c->dProbe.p); }
+		}
+		q0 = q1;
+	}
+	{ ScopedK t(c->timer, "k_probe_count");
+	  hipLaunchKernelGGL(k_probe_count, nq, WG, 0, s, c->dQKmerOff.p, c->dProbe.p, c->dCntA.p, c->dCntB.p); }
+}
+
 // Device part of one chunk of queries [qa, qb): seed collection -> sort -> groups ->
 // chaining -> (edit distance) -> compacted primaries in c->hPrim / offsets in c->hOff.
 // Returns false (nothing done) when the chunk's hits exceed the budget and it can be split.
@@ -872,6 +994,11 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64* qWords = c->hasQ ? c->dQWords.p : c->dWords.p;
 	const u64* qWordOff = c->hasQ ? c->dQWordOff.p : c->dWordOff.p;
 	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
+	// a table beyond the Infinity Cache is probed region by region (FG_PROBE_PARTITION = 0 / 1 overrides)
+	const bool partition = !c->tableWide && c->k <= 17 &&
+		(getenv("FG_PROBE_PARTITION") ? atoi(getenv("FG_PROBE_PARTITION")) != 0 : c->tableSlots * 8 > (1ULL << 30));
+	if (partition) probePartitioned(c, nq, localOff.data(), qWords, qWordOff, qLen);
+	else
 	{ ScopedK t(c->timer, "k_probe");
 	  if (c->tableWide)
 		hipLaunchKernelGGL(k_probe<true>, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,

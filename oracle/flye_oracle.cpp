@@ -801,6 +801,31 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			if (maxScore > k) S.back[i] = maxId;
 		}
 
+		if (getenv("FO_STATS4"))
+		{
+			// how often are the two per-group sorts free of ties that could matter?  (a) ext re-sort: duplicate
+			// extPos; (b) score-order sort: two elements with a back pointer sharing a score
+			static std::atomic<unsigned long long> G[8];	// groups, elems, extSorted groups, their elems, ext-tie groups, their elems, score-tie groups, their elems
+			G[0] += 1; G[1] += n;
+			if (extSorted)
+			{
+				G[2] += 1; G[3] += n;
+				bool tie = false;
+				for (int32_t t = 1; t < n; ++t) if (M[t].ext == M[t - 1].ext) { tie = true; break; }
+				if (tie) { G[4] += 1; G[5] += n; }
+			}
+			std::vector<int32_t> live;
+			for (int32_t t = 0; t < n; ++t) if (S.back[t] != -1) live.push_back(S.score[t]);
+			std::sort(live.begin(), live.end());
+			bool stie = false;
+			for (size_t t = 1; t < live.size(); ++t) if (live[t] == live[t - 1]) { stie = true; break; }
+			if (stie) { G[6] += 1; G[7] += n; }
+			if ((G[0] & 0x3FFF) == 0)
+				fprintf(stderr, "groups %llu elems %llu | extSorted %llu (%llu el), with ext ties %llu (%llu el) | score ties among back!=-1: %llu (%llu el)\n",
+						(unsigned long long)G[0], (unsigned long long)G[1], (unsigned long long)G[2], (unsigned long long)G[3],
+						(unsigned long long)G[4], (unsigned long long)G[5], (unsigned long long)G[6], (unsigned long long)G[7]);
+		}
+
 		// backtracking in descending score order (:326-427)
 		S.order.resize(n);
 		std::iota(S.order.begin(), S.order.end(), 0);

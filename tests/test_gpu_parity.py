@@ -858,3 +858,70 @@ def test_kmer_counter_forms_agree(built, golden_cases, monkeypatch, mode):
     kt = ctx.kernel_times()
     assert "k_count" in kt
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["raw_ont_rc", "hifi", "raw_local"])
+def test_partitioned_probes_are_invisible(built, golden_cases, monkeypatch, name):
+    """A lookup table beyond the caches is probed region by region (the probes of a batch are radix-partitioned by
+    table region first, fg_overlap.hip k_probe_emit / k_probe_sorted).  Forced on at golden-case size, in several
+    sub-batches: same records, reverse-complement queries and self hits included."""
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    from flye_amd import config
+    cfg = config.preset(case["preset"])
+    monkeypatch.setenv("FG_PROBE_PARTITION", "1")
+    monkeypatch.setenv("FG_PROBE_SUB_KMERS", str(int(rs.total_bases) // 7))
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
+                                  maxOverlaps=case.get("max_overlaps", 0))
+    assert res.lines() == golden_lines(name)
+    assert "k_probe_emit" in ctx.kernel_times()
+    ctx.close()
+
+
+def test_bridge_bulk_mode_for_unpredictable_walks(built):
+    """A caller that asks for the container's reads in an order nobody can guess (Extender starts from the reads in
+    hash order, extender.cpp:376-381; estimateGlobalCoverage picks them with rand(), chimera.cpp:76): after
+    FGB_BULK_TRIGGER requests of a class the dispatcher computes ALL forward records of that class in a few large
+    device calls and answers from them.  Lists stay the direct ones, in both classes the assemble stage uses."""
+    import itertools
+    import threading
+    from flye_amd import config, gpu, synth
+    rs = synth.simulate(seed=41, genome_len=150_000, coverage=30, kind="pb_raw", n_tandems=20).filter_min_len(1000)
+    cfg = config.preset("raw")
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = 0.3
+    fwd = np.arange(0, 2 * rs.n, 2, dtype=np.uint32)
+    direct = {0: det.getSeqOverlapsBatch(fwd), 100: det.getSeqOverlapsBatch(fwd, maxOverlaps=100)}
+    oc = gpu.BatchingOverlapContainer(det, max_batch=64, linger_us=100)
+    order = np.random.default_rng(3).permutation(len(fwd))
+    errors = []
+    counter = itertools.count()
+    lock = threading.Lock()
+
+    def worker():
+        try:
+            while True:
+                with lock:
+                    j = next(counter)
+                if j >= 2 * len(order):
+                    return
+                mo = 0 if j % 2 == 0 else 100
+                i = int(order[j // 2])
+                got = oc.quickSeqOverlaps(int(fwd[i]), mo, False)
+                assert got.tobytes() == direct[mo].of(i).tobytes(), (i, mo)
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker) for _ in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    s = oc.stats()
+    assert s["requests"] == 2 * len(fwd)
+    assert s["ahead_hits"] > 0.8 * s["requests"], s
+    assert s["device_calls"] < 0.1 * s["requests"], s
+    oc.close()
+    ctx.close()
