@@ -97,8 +97,10 @@ struct SpecClass {
 	// asked for (at most `bulkMaxRecs` overlaps waiting).
 	uint64_t requests = 0;
 	bool bulk = false;
-	uint32_t bulkNext = 0;				// next forward read (index) the bulk pass looks at
-	std::vector<uint8_t> done;			// per forward read: a result of this class exists (stored or handed out)
+	uint32_t bulkNext = 0;				// next record the bulk pass looks at: the forward records first (0 .. n), then -- if
+										// reverse-complement records were asked for in this class -- those (n .. 2n)
+	uint64_t rcRequests = 0;
+	std::vector<uint8_t> done;			// per record (id - first id): a result of this class exists (stored or handed out)
 	uint64_t readyRecs = 0;				// overlaps in `ready`
 };
 
@@ -309,19 +311,20 @@ void fgb_container::run()
 					{
 						// every forward record not computed yet, bulkBatch per call, while the store has room
 						uint32_t added = 0;
-						if (sc.done.size() < cnt) sc.done.resize(cnt, 0);
-						while (sc.readyRecs < bulkMaxRecs && added < bulkBatch && sc.bulkNext < cnt)
+						if (sc.done.size() < 2 * (size_t)cnt) sc.done.resize(2 * (size_t)cnt, 0);
+						const uint32_t bulkEnd = sc.rcRequests ? 2 * cnt : cnt;
+						while (sc.readyRecs < bulkMaxRecs && added < bulkBatch && sc.bulkNext < bulkEnd)
 						{
 							const uint32_t idx = sc.bulkNext++;
-							const uint32_t id = base + 2u * idx;
-							if (sc.done[idx] || sc.ready.find(id) != sc.ready.end()) continue;
+							const uint32_t id = idx < cnt ? base + 2u * idx : base + 2u * (idx - cnt) + 1u;
+							if (sc.done[id - base] || sc.ready.find(id) != sc.ready.end()) continue;
 							bool asked = false;
 							for (QuickReq* r : kv.second) asked |= r->id == id;
 							if (asked) continue;
 							ids.push_back(id); ++added;
 						}
 						nbStart[kv.first] = ids.size();
-						if (sc.bulkNext < cnt && sc.readyRecs < bulkMaxRecs) sc.wanted = true;	// the next batch follows at once
+						if (sc.bulkNext < bulkEnd && sc.readyRecs < bulkMaxRecs) sc.wanted = true;	// the next batch follows at once
 						continue;
 					}
 					for (int strand = 0; strand < 2; ++strand)
@@ -431,7 +434,7 @@ void fgb_container::run()
 					for (size_t i = 0; i < kv.second.size(); ++i)
 					{
 						sc.readyRecs += kv.second[i]->recs.size();
-						if (sc.bulk && !(ids[i] & 1u) && ids[i] >= firstId && (ids[i] - firstId) / 2 < sc.done.size()) sc.done[(ids[i] - firstId) / 2] = 1;
+						if (sc.bulk && ids[i] >= firstId && ids[i] - firstId < sc.done.size()) sc.done[ids[i] - firstId] = 1;
 						sc.ready[ids[i]] = SpecEntry{std::move(kv.second[i]), (uint8_t)(i >= nb0 ? 1 : 0)};
 						sc.order.push_back(ids[i]);
 						sc.seen[ids[i]] = 1;
@@ -479,6 +482,7 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 		if (c->bulkTrigger && c->inIndexed(r.id) && !c->qNFwd)
 		{
 			SpecClass& cls = c->spec[std::make_pair(r.maxOverlaps, r.forceLocal)];
+			if (r.id & 1u) ++cls.rcRequests;
 			if (++cls.requests >= c->bulkTrigger && !cls.bulk) { cls.bulk = true; cls.wanted = true; c->cvWork.notify_one(); }
 		}
 		auto sit = c->spec.find(std::make_pair(r.maxOverlaps, r.forceLocal));
@@ -497,7 +501,7 @@ static int quickCommon(fgb_container* c, QuickReq& r)
 				if (r.maxOverlaps == 0 && !r.forceLocal && !sc.bulk) c->queueNeighbours(sc, r.res->recs);	// what the caller asks for next
 				// keep the device ahead of the callers: top up when half of the last call's results are gone
 				// (bulk mode: when the store has room again)
-				if (sc.bulk) { if (!sc.wanted && sc.bulkNext < c->nFwd && sc.readyRecs < c->bulkMaxRecs) { sc.wanted = true; c->cvWork.notify_one(); } }
+				if (sc.bulk) { if (!sc.wanted && sc.bulkNext < (sc.rcRequests ? 2 * c->nFwd : c->nFwd) && sc.readyRecs < c->bulkMaxRecs) { sc.wanted = true; c->cvWork.notify_one(); } }
 				else
 				if (!sc.wanted && sc.ready.size() * 2 < sc.ahead) { sc.wanted = true; c->cvWork.notify_one(); }
 				r.done = true; r.status = FG_OK;

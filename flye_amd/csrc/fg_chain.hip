@@ -801,7 +801,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	{
 		hipStream_t sBig = fork(nPrep[0] && nPrep[1]);
 		const u32* prepList[2] = {c->dListSmall.p, c->dListBig.p};
-#define PREP_ARGS(view, cls) cp, prepList[cls], nPrep[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
+#define PREP_ARGS(view, cls) cp, prepList[cls], nPrep[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, qLen, \
 		view, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p
 		for (int cls = 1; cls >= 0; --cls)
 		{
@@ -847,9 +847,9 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 		HIP_CHECK(hipStreamWaitEvent(c->stream3, c->evFork, 0));
 		sMid = c->stream2; sHuge = c->stream3;
 	}
-#define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, \
+#define FIN_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, \
 		qLen, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
-#define DP_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->dQuery.p, c->dLen.p, qLen, \
+#define DP_ARGS(cls) cp, lists[cls], hc[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, qLen, \
 		c->dGroupExtSorted.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p
 	for (int cls = 2; cls >= 1; --cls)	// the longest chains first
 	{

@@ -325,6 +325,7 @@ struct fg_ctx {
 
 	// overlap-stage scratch (grow-only)
 	DevBuf<u32> dQuery;			// query record indices
+	const u32* curQuery = nullptr;	// ... of the sub-range of the chunk the stage is working on (group / primary records index it)
 	DevBuf<u64> dQKmerOff;		// per query prefix of k-mer counts
 	DevBuf<u64> dProbe;			// per query k-mer: table value (0 = miss)
 	// probes partitioned by table region (tables beyond the caches): (region | k-mer, position) pairs, twice, + sort scratch
@@ -494,6 +495,28 @@ __device__ __forceinline__ void fg_kmer_pair(const u64* __restrict__ w, i32 q, i
 	rv = ~x & mask;
 }
 
+// the slot of `key` in part p of a narrow table, starting at group g: the slot's value, or FG_EMPTY_KEY when absent
+__device__ __forceinline__ u64 fg_probe_slot(const FgTable& T, u32 p, u32 g, u64 key)
+{
+	const u32 nGroups = T.groups[p];
+	while (true)
+	{
+		const ulonglong2* grp = (const ulonglong2*)(T.slots + T.slotBase[p] + (u64)g * 8u);
+		const ulonglong2 a = grp[0], b = grp[1], c = grp[2], d = grp[3];
+		const u64 sl[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+		u64 hit = FG_EMPTY_KEY;
+		bool empty = false;
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+		{
+			if ((sl[i] >> FG_IDX_BITS) == key) hit = sl[i];
+			empty |= sl[i] == FG_EMPTY_KEY;
+		}
+		if (hit != FG_EMPTY_KEY || empty) return hit;
+		g = g + 1 == nGroups ? 0 : g + 1;
+	}
+}
+
 // probe: returns off << 24 | cnt of the k-mer's list, FG_CNT_REPETITIVE in the low bits for a k-mer of
 // _repetitiveKmers, or 0 when absent.  One 8-byte slot read decides a miss (4 in 5 query k-mers: the
 // table is half the size of a 16-byte layout -- E. coli 50x: 134 MB, inside the 256 MiB Infinity Cache);
@@ -524,29 +547,12 @@ __device__ __forceinline__ u64 fg_probe(const FgTable& T, u64 key)
 	}
 	// narrow: the key's 8-slot group is one 64-byte line, fetched whole; insertion fills a group before it
 	// spills into the next, so an empty slot anywhere in the group settles a miss without a second access
-	while (true)
-	{
-		const ulonglong2* grp = (const ulonglong2*)(T.slots + T.slotBase[p] + (u64)g * 8u);
-		const ulonglong2 a = grp[0], b = grp[1], c = grp[2], d = grp[3];
-		const u64 sl[8] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-		u64 hit = FG_EMPTY_KEY;
-		bool empty = false;
-#pragma unroll
-		for (int i = 0; i < 8; ++i)
-		{
-			if ((sl[i] >> FG_IDX_BITS) == key) hit = sl[i];
-			empty |= sl[i] == FG_EMPTY_KEY;
-		}
-		if (hit != FG_EMPTY_KEY)
-		{
-			if ((hit & FG_IDX_MASK) == FG_IDX_MASK) return FG_CNT_REPETITIVE;
-			const u64 idx = T.keyBase[p] + (hit & FG_IDX_MASK);
-			const u64 o = T.keyOff[idx];
-			return (o << FG_CNT_BITS) | (T.keyOff[idx + 1] - o);
-		}
-		if (empty) return 0;
-		g = g + 1 == nGroups ? 0 : g + 1;
-	}
+	const u64 hit = fg_probe_slot(T, p, g, key);
+	if (hit == FG_EMPTY_KEY) return 0;
+	if ((hit & FG_IDX_MASK) == FG_IDX_MASK) return FG_CNT_REPETITIVE;
+	const u64 idx = T.keyBase[p] + (hit & FG_IDX_MASK);
+	const u64 o = T.keyOff[idx];
+	return (o << FG_CNT_BITS) | (T.keyOff[idx + 1] - o);
 }
 
 #endif // __HIPCC__

@@ -553,7 +553,7 @@ void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc)
 	c->dEditScratch.reserve((size_t)grid * 2 * (2 * eMax + 5));
 	c->dEditList.reserve(2 * nPrim + 2);
 	c->dEditCnt.reserve(sizeof(EdCounters));
-	EdSeqs S{c->dQuery.p, c->hasQ ? c->dQWords.p : c->dWords.p, c->hasQ ? c->dQWordOff.p : c->dWordOff.p,
+	EdSeqs S{c->curQuery, c->hasQ ? c->dQWords.p : c->dWords.p, c->hasQ ? c->dQWordOff.p : c->dWordOff.p,
 			 c->hasQ ? c->dQLen.p : c->dLen.p, c->dWords.p, c->dWordOff.p, c->dLen.p, c->firstId};
 	u32* listSmall = c->dEditList.p;
 	u32* listBig = c->dEditList.p + nPrim + 1;
@@ -610,6 +610,7 @@ void fgDebugEditDistances(fg_ctx* c, u32 nPairs, int useHpc, i32* outDist, i32* 
 	c->dQuery.reserve(nPairs);
 	HIP_CHECK(hipMemcpyAsync(dPrims.p, h.data(), (size_t)nPairs * sizeof(PrimRec), hipMemcpyHostToDevice, s));
 	HIP_CHECK(hipMemcpyAsync(c->dQuery.p, q.data(), nPairs * 4ULL, hipMemcpyHostToDevice, s));
+	c->curQuery = c->dQuery.p;
 	c->timer.reset();
 	fgEditDistances(c, (PrimRec*)dPrims.p, nPairs, useHpc);
 	HIP_CHECK(hipMemcpyAsync(h.data(), dPrims.p, (size_t)nPairs * sizeof(PrimRec), hipMemcpyDeviceToHost, s));

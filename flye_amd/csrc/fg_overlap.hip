@@ -200,12 +200,24 @@ __global__ void k_probe_emit(u32 q0, const u32* __restrict__ query, const u64* _
 }
 
 __global__ void k_probe_sorted(const u64* __restrict__ keys, const u64* __restrict__ vals, u64 n, FgTable table,
-							   u64* __restrict__ probe)
+							   u64* __restrict__ probe, int ablate)
 {
 	const u64 i = (u64)blockIdx.x * WG + threadIdx.x;
 	if (i >= n) return;
-	u64 v = fg_probe<false>(table, keys[i] & ((1ULL << PART_KEY_BITS) - 1));
+	u64 v;
+	if (ablate & 2)
+	{
+		// timing experiment (results become wrong): the table lines only, no list bounds
+		const u64 key = keys[i] & ((1ULL << PART_KEY_BITS) - 1);
+		u32 part = 0;
+		if (table.nParts > 1)
+			while (part + 1 < table.nParts && key >= table.bound[part + 1]) ++part;
+		const u64 hit = fg_probe_slot(table, part, __umulhi((u32)(fg_mix(key) >> 32), table.groups[part]), key);
+		v = hit == FG_EMPTY_KEY ? 0 : ((hit & FG_IDX_MASK) << FG_CNT_BITS | 1);
+	}
+	else v = fg_probe<false>(table, keys[i] & ((1ULL << PART_KEY_BITS) - 1));
 	if (v == 0) return;
+	if (ablate & 1) { if (v == 12345) probe[0] = v; return; }		// timing experiment: no scatter
 	const u64 val = vals[i];
 	if ((u32)(v & FG_CNT_MASK) != FG_CNT_REPETITIVE) v |= val & (FLAG_SELF | FLAG_FLIP);
 	probe[val & ~(FLAG_SELF | FLAG_FLIP)] = v;
@@ -960,7 +972,8 @@ static void probePartitioned(fg_ctx* c, u32 nq, const u64* localOff, const u64* 
 											 PART_KEY_BITS + PROBE_REGION_BITS, c->dPartScratch.p); }
 			{ ScopedK t(c->timer, "k_probe");
 			  hipLaunchKernelGGL(k_probe_sorted, (unsigned)((n + WG - 1) / WG), WG, 0, s, which ? c->dPartK1.p : c->dPartK0.p,
-								 which ? c->dPartV1.p : c->dPartV0.p, n, c->table, c->dProbe.p); }
+								 which ? c->dPartV1.p : c->dPartV0.p, n, c->table, c->dProbe.p,
+								 getenv("FG_ABLATE_PROBE") ? atoi(getenv("FG_ABLATE_PROBE")) : 0); }
 		}
 		q0 = q1;
 	}
@@ -973,8 +986,12 @@ static void probePartitioned(fg_ctx* c, u32 nq, const u64* localOff, const u64* 
 // Returns false (nothing done) when the chunk's hits exceed the budget and it can be split.
 struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems, nMatchSlots; };
 
-static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, const u32* hq,
-						const u64* hQKmerOff, u32 qa, u32 qb, u64 hitBudget, u64 primBase, ChunkResult* res)
+// Probe step of one chunk of queries [qa, qb) (bounded by the k-mer budget): every query k-mer's table value in
+// c->dProbe, hits / repetitive positions per query in c->dCntA / c->dCntB; hitsPerQuery = the former on the host.
+// The chunk's hits may exceed the hit budget: the caller then runs the rest of the stage over sub-ranges of the
+// chunk's queries -- the probes are NOT repeated (they were, once per halving, until round 3: a D. melanogaster-
+// sized pass probed every read four times).
+static void probeChunk(fg_ctx* c, const u32* hq, const u64* hQKmerOff, u32 qa, u32 qb, std::vector<u64>& hitsPerQuery)
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
@@ -994,9 +1011,10 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	const u64* qWords = c->hasQ ? c->dQWords.p : c->dWords.p;
 	const u64* qWordOff = c->hasQ ? c->dQWordOff.p : c->dWordOff.p;
 	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
-	// a table beyond the Infinity Cache is probed region by region (FG_PROBE_PARTITION = 0 / 1 overrides)
+	// FG_PROBE_PARTITION=1: probes ordered by table region first (measured, D. melanogaster-sized table of 9 GB:
+	// 26 ms against 20 ms in query order per 0.48 G probes -- the table lines are not what the probe waits for)
 	const bool partition = !c->tableWide && c->k <= 17 &&
-		(getenv("FG_PROBE_PARTITION") ? atoi(getenv("FG_PROBE_PARTITION")) != 0 : c->tableSlots * 8 > (1ULL << 30));
+		(getenv("FG_PROBE_PARTITION") ? atoi(getenv("FG_PROBE_PARTITION")) != 0 : false);
 	if (partition) probePartitioned(c, nq, localOff.data(), qWords, qWordOff, qLen);
 	else
 	{ ScopedK t(c->timer, "k_probe");
@@ -1008,12 +1026,28 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 		hipLaunchKernelGGL(k_probe<false>, nq, WG, 0, s, c->dQuery.p, qWords, qWordOff, qLen, c->dKmerOff.p,
 						   c->dQKmerOff.p, k, c->table, c->hasQ ? (const u32*)nullptr : c->dIndexedBits.p,
 						   c->dProbe.p, c->dCntA.p, c->dCntB.p); }
+	hitsPerQuery.resize(nq);
+	HIP_CHECK(hipMemcpyAsync(hitsPerQuery.data(), c->dCntA.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// The stage behind the probes for the queries [sub0, sub0 + nq) of the probed chunk: seed expansion -> sort ->
+// groups -> chaining -> (edit distance) -> compacted primaries in c->hPrim (behind primBase records) / offsets in
+// c->hOff.
+static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u32 sub0, u32 nq, u64 primBase,
+					  ChunkResult* res)
+{
+	hipStream_t s = c->stream;
+	const int k = c->k;
+	const u32* dQuery = c->dQuery.p + sub0;
+	const u64* dQKmerOff = c->dQKmerOff.p + sub0;		// values index the chunk's probe array
+	c->curQuery = dQuery;
+	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
 	{ ScopedK t(c->timer, "k_exscan");
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p, c->dHitOff.p, nq);
-	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p, c->dFiltOff.p, nq); }
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p + sub0, c->dHitOff.p, nq);
+	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p + sub0, c->dFiltOff.p, nq); }
 	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
 	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
-	if (nHits > hitBudget && nq > 1) return false;
 	res->nHits = nHits;
 	c->dFiltPos.reserve(nFilt + 1);
 	// 32-bit sort keys when (record index, query position) fit together
@@ -1031,7 +1065,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	{
 		c->dHitKey32.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
-		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
+		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u32>(c, c->dHitOff.p, nq, c->dHitKey32.p, c->dHitVal.p, nHits);
 	}
@@ -1039,7 +1073,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	{
 		c->dHitKey.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
-		  hipLaunchKernelGGL(k_fill<PK>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, curBits,
+		  hipLaunchKernelGGL(k_fill<PK>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, (PK*)c->dHitKey.p, (u32*)nullptr, c->dFiltPos.p); }
 		sortSegments<PK>(c, c->dHitOff.p, nq, (PK*)c->dHitKey.p, (u32*)nullptr, nHits, curBits);
 	}
@@ -1047,7 +1081,7 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	{
 		c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
 		{ ScopedK t(c->timer, "k_fill");
-		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, c->dQuery.p, c->dLen.p, qLen, c->dQKmerOff.p, k, c->firstId, 0,
+		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
 		sortSegments<u64>(c, c->dHitOff.p, nq, c->dHitKey.p, c->dHitVal.p, nHits, curBits);
 	}
@@ -1138,7 +1172,6 @@ static bool deviceChunk(fg_ctx* c, const fg_detector_params* p, uint8_t forceLoc
 	res->nPrim = nPrim;
 	res->dpGroups = 0; res->dpElems = 0;
 	for (u32 i = 0; i < nq; ++i) { res->dpGroups += c->hOff.p[(nq + 1) + i]; res->dpElems += c->hOff.p[2 * (size_t)(nq + 1) + i]; }
-	return true;
 }
 
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
@@ -1209,9 +1242,8 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		hitBudget = std::min(hitBudget, std::max<u64>(16ULL << 20, usable / 100 * 85 / 80));	// ~70 B per hit, grow-only slack
 		kmerBudget = std::min(kmerBudget, std::max<u64>(16ULL << 20, usable / 100 * 15 / 9));	// 8 B per query k-mer
 	}
-	std::vector<std::pair<u32, u32>> todo;	// stack of [qa, qb)
+	std::vector<std::pair<u32, u32>> chunks;	// [qa, qb) bounded by the k-mer budget
 	{
-		std::vector<std::pair<u32, u32>> chunks;
 		u32 qa = 0;
 		while (qa < nq)
 		{
@@ -1220,40 +1252,44 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			chunks.push_back({qa, qb});
 			qa = qb;
 		}
-		for (size_t i = chunks.size(); i-- > 0;) todo.push_back(chunks[i]);
 	}
 	const bool keepAln = p->keep_alignment;
 	std::vector<u64> mData, mOff(1, 0);	// keep_alignment: compacted kmerMatches per primary
 	std::vector<u64> primOffAll(nq + 1, 0);
+	std::vector<u64> hitsPerQuery;
 	u64 nPrim = 0;
 	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0;
-	while (!todo.empty())
+	for (const auto& ch : chunks)
 	{
-		const auto [qa, qb] = todo.back();
-		todo.pop_back();
-		ChunkResult cr;
-		if (!deviceChunk(c, p, forceLocal, hq.data(), hQKmerOff.data(), qa, qb, hitBudget, nPrim, &cr))
+		probeChunk(c, hq.data(), hQKmerOff.data(), ch.first, ch.second, hitsPerQuery);
+		// sub-ranges of the chunk's queries whose hits fit the budget (a single query above it is one of its own)
+		const u32 cn = ch.second - ch.first;
+		u32 sa = 0;
+		while (sa < cn)
 		{
-			const u32 mid = qa + (qb - qa) / 2;
-			todo.push_back({mid, qb});
-			todo.push_back({qa, mid});
-			continue;
-		}
-		out->seed_hits += cr.nHits; out->dp_groups += cr.dpGroups; out->dp_elements += cr.dpElems;
-		const u64* off = c->hOff.p;
-		for (u32 i = 0; i < qb - qa; ++i) primOffAll[qa + i + 1] = nPrim + off[i + 1];
-		if (keepAln)
-		{
-			mData.reserve(mData.size() + cr.nMatchSlots);
-			for (u64 j = 0; j < cr.nPrim; ++j)
+			u32 sb = sa + 1;
+			u64 acc = hitsPerQuery[sa];
+			while (sb < cn && acc + hitsPerQuery[sb] <= hitBudget) acc += hitsPerQuery[sb++];
+			const u32 qa = ch.first + sa, qb = ch.first + sb;
+			ChunkResult cr;
+			deviceSub(c, p, forceLocal, sa, sb - sa, nPrim, &cr);
+			out->seed_hits += cr.nHits; out->dp_groups += cr.dpGroups; out->dp_elements += cr.dpElems;
+			const u64* off = c->hOff.p;
+			for (u32 i = 0; i < qb - qa; ++i) primOffAll[qa + i + 1] = nPrim + off[i + 1];
+			if (keepAln)
 			{
-				const u64 slotEnd = c->hMatchOff.p[j + 1];
-				const u32 cnt = c->hMatchCnt.p[j];
-				mData.insert(mData.end(), c->hMatches.p + slotEnd - cnt, c->hMatches.p + slotEnd);
-				mOff.push_back(mData.size());
+				mData.reserve(mData.size() + cr.nMatchSlots);
+				for (u64 j = 0; j < cr.nPrim; ++j)
+				{
+					const u64 slotEnd = c->hMatchOff.p[j + 1];
+					const u32 cnt = c->hMatchCnt.p[j];
+					mData.insert(mData.end(), c->hMatches.p + slotEnd - cnt, c->hMatches.p + slotEnd);
+					mOff.push_back(mData.size());
+				}
 			}
+			nPrim += cr.nPrim;
+			sa = sb;
 		}
-		nPrim += cr.nPrim;
 	}
 	HIP_CHECK(hipEventRecord(evB, s));
 	// no wait for the last chunk's records here: piece by piece in the shim's first pass
