@@ -742,6 +742,15 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 		S.score.assign(n, 0);
 		S.back.assign(n, -1);
 		const bool extSorted = extLen > curLen;
+		if (extSorted && getenv("FO_STATS4"))
+		{
+			static std::atomic<unsigned long long> A[4];	// ext-sorted groups, elems, already strictly ascending groups, elems
+			bool asc = true;
+			for (size_t t = 1; t < M.size(); ++t) if (M[t].ext <= M[t - 1].ext) { asc = false; break; }
+			A[0] += 1; A[1] += M.size(); if (asc) { A[2] += 1; A[3] += M.size(); }
+			if ((A[0] & 0x1FFF) == 0) fprintf(stderr, "ext-sorted groups %llu (%llu el): already strictly ascending %llu (%llu el)\n",
+				(unsigned long long)A[0], (unsigned long long)A[1], (unsigned long long)A[2], (unsigned long long)A[3]);
+		}
 		if (extSorted)
 			std::sort(M.begin(), M.end(), [](const Hit& a, const Hit& b) { return a.ext < b.ext; });
 
