@@ -411,6 +411,8 @@ def cpu_reference(rs, preset, min_ovlp, queries, gres, threads, sample_bp=250e6)
             except Exception as e:  # noqa: BLE001
                 seam = {"error": str(e)[:200]}
     return {"value": round(info["queried_bp"] / info["overlap_s"] / 1e9, 6), "unit": "Gbp/s", "cores": threads,
+            # its own index build + its overlap stage over the same reads: what work.end_to_end_gbps stands beside
+            "end_to_end_gbps": (round(info["queried_bp"] / (info["index_s"] + info["overlap_s"]) / 1e9, 6) if n == len(queries) else None),
             "reference_program_with_device_seams": seam,
             "kind": "reference", "overlap_s": info["overlap_s"], "index_s": info["index_s"], "load_s": info["load_s"],
             "overlaps": info["overlaps"],
