@@ -782,10 +782,11 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	c->dListSmall.reserve(nGroups + 1); c->dListBig.reserve(nGroups + 1); c->dListDp.reserve(nGroups + 1);
 	c->dGroupExtSorted.reserve(nGroups + 1);
 	c->dListCnt.reserve(4);
-	c->dCur.reserve(nHits + 16); c->dExt.reserve(nHits + 16);
-	c->dScore.reserve(nHits + 16); c->dBack.reserve(nHits + 16);
-	c->dTmp32.reserve(4 * nHits + 16);
-	c->dCand.reserve(nHits + 1);
+	const u64 hitCap = std::max<u64>(nHits, c->hitCapHint);	// sized once for the largest sub-range of the chunk
+	c->dCur.reserve(hitCap + 16); c->dExt.reserve(hitCap + 16);
+	c->dScore.reserve(hitCap + 16); c->dBack.reserve(hitCap + 16);
+	c->dTmp32.reserve(4 * hitCap + 16);
+	c->dCand.reserve(hitCap + 1);
 	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");

@@ -69,12 +69,18 @@ template <class T>
 struct DevBuf {
 	T* p = nullptr;
 	size_t n = 0;
+	bool owned = true;		// false: a view of another context's buffer (the second lane of fg_overlaps)
 	DevBuf() {}
 	DevBuf(const DevBuf&) = delete;
 	DevBuf& operator=(const DevBuf&) = delete;
 	~DevBuf() { release(); }
-	void release() { if (p) { (void)hipFree(p); fgDevAccount(-(long long)(n * sizeof(T))); p = nullptr; n = 0; } }
-	void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+	void release()
+	{
+		if (p && owned) { (void)hipFree(p); fgDevAccount(-(long long)(n * sizeof(T))); }
+		p = nullptr; n = 0; owned = true;
+	}
+	void alias(const DevBuf& o) { release(); p = o.p; n = o.n; owned = false; }
+	void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(owned, o.owned); }
 	void alloc(size_t count)
 	{
 		release();
@@ -316,6 +322,9 @@ struct fg_ctx {
 	FgTable table{};
 	DevBuf<u32> dIndexedBits;	// one bit per forward k-mer position: contributes an entry
 
+	// second lane of fg_overlaps: a context of its own scratch, streams and timers whose read / index / probe buffers
+	// are views of this one's (fg_overlap.hip: sub-ranges of a call's queries run on two lanes side by side)
+	std::unique_ptr<fg_ctx> lane2;
 	std::shared_ptr<void> indexBuild;	// state between the steps of an index build (fg_index.hip)
 	// between fg_index_gather_begin and _end: this context's own piece of a sharded build, set aside while the
 	// arrays above are the full-size ones the ranks' pieces are gathered into
@@ -325,6 +334,7 @@ struct fg_ctx {
 
 	// overlap-stage scratch (grow-only)
 	DevBuf<u32> dQuery;			// query record indices
+	u64 hitCapHint = 0;			// hits of the largest sub-range of the chunk in work (per-hit scratch is reserved for it)
 	const u32* curQuery = nullptr;	// ... of the sub-range of the chunk the stage is working on (group / primary records index it)
 	DevBuf<u64> dQKmerOff;		// per query prefix of k-mer counts
 	DevBuf<u64> dProbe;			// per query k-mer: table value (0 = miss)

@@ -840,7 +840,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	// pieces are disjoint; even the median-of-3 killer stays far below one task per 8 hits
 	const u32 smallCap = (u32)std::min<u64>(nHits / 8 + 4ULL * nSeg + 1024, 0x7fffffffULL);
 	const u64 bigCap = nHits / SORT_CAP + nSeg + 16;
-	c->dTmp32.reserve(2 * nHits + 2);
+	c->dTmp32.reserve(std::max<u64>(2 * nHits + 2, 4 * c->hitCapHint + 16));	// the chaining stage wants 4 per hit of it: sized once
 	c->dSortTasks.reserve((size_t)smallCap * sizeof(SortTask));
 	c->dSortBig.reserve((size_t)(6 * bigCap) * sizeof(SortTask));
 	c->dListCnt.reserve(4);
@@ -1035,7 +1035,7 @@ static void probeChunk(fg_ctx* c, const u32* hq, const u64* hQKmerOff, u32 qa, u
 // groups -> chaining -> (edit distance) -> compacted primaries in c->hPrim (behind primBase records) / offsets in
 // c->hOff.
 static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u32 sub0, u32 nq, u64 primBase,
-					  ChunkResult* res)
+					  u64 hitCapHint /* the largest sub-range of the chunk: scratch is sized once, not regrown */, ChunkResult* res)
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
@@ -1043,12 +1043,19 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	const u64* dQKmerOff = c->dQKmerOff.p + sub0;		// values index the chunk's probe array
 	c->curQuery = dQuery;
 	const i32* qLen = c->hasQ ? c->dQLen.p : c->dLen.p;
+	// per-query scratch of THIS lane (the probe step reserved the first lane's for the whole chunk)
+	c->dHitOff.reserve(nq + 1); c->dFiltOff.reserve(nq + 1);
+	c->dGroupCnt.reserve(nq + 1); c->dGroupOff.reserve(nq + 1);
+	c->dPrimCnt.reserve(nq + 1); c->dPrimOff.reserve(nq + 1); c->dDpGroups.reserve(nq + 1); c->dDpElems.reserve(nq + 1);
+	c->dListCnt.reserve(4);
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntA.p + sub0, c->dHitOff.p, nq);
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dCntB.p + sub0, c->dFiltOff.p, nq); }
 	const u64 nHits = fetchScalar(c, c->dHitOff.p + nq);
 	const u64 nFilt = fetchScalar(c, c->dFiltOff.p + nq);
 	res->nHits = nHits;
+	const u64 hitCap = std::max(nHits, hitCapHint);		// what the per-hit buffers below are reserved for
+	c->hitCapHint = hitCap;
 	c->dFiltPos.reserve(nFilt + 1);
 	// 32-bit sort keys when (record index, query position) fit together
 	int curBits = 1, recBits = 1;
@@ -1063,7 +1070,7 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	const int keyMode = key32 ? 0 : ((canPack && wantPack) ? 1 : 2);
 	if (keyMode == 0)
 	{
-		c->dHitKey32.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
+		c->dHitKey32.reserve(hitCap + 1); c->dHitVal.reserve(hitCap + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u32>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey32.p, c->dHitVal.p, c->dFiltPos.p); }
@@ -1071,7 +1078,7 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	}
 	else if (keyMode == 1)
 	{
-		c->dHitKey.reserve(nHits + 1);
+		c->dHitKey.reserve(hitCap + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<PK>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, curBits,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, (PK*)c->dHitKey.p, (u32*)nullptr, c->dFiltPos.p); }
@@ -1079,7 +1086,7 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	}
 	else
 	{
-		c->dHitKey.reserve(nHits + 1); c->dHitVal.reserve(nHits + 1);
+		c->dHitKey.reserve(hitCap + 1); c->dHitVal.reserve(hitCap + 1);
 		{ ScopedK t(c->timer, "k_fill");
 		  hipLaunchKernelGGL(k_fill<u64>, nq, WG, 0, s, dQuery, c->dLen.p, qLen, dQKmerOff, k, c->firstId, 0,
 							 c->dProbe.p, c->dEntries.p, c->dHitOff.p, c->dFiltOff.p, c->dHitKey.p, c->dHitVal.p, c->dFiltPos.p); }
@@ -1174,12 +1181,67 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	for (u32 i = 0; i < nq; ++i) { res->dpGroups += c->hOff.p[(nq + 1) + i]; res->dpElems += c->hOff.p[2 * (size_t)(nq + 1) + i]; }
 }
 
+// ---- two lanes ------------------------------------------------------------------------------------------------
+// The stage behind the probes alternates between bandwidth-bound kernels (seed expansion, the sort levels) and
+// issue- / latency-bound ones that end on a handful of long waves (the per-group kernels of the chaining stage).  A call
+// with enough hits is therefore cut into a few sub-ranges that two LANES work through side by side: the second lane is
+// a context of its own scratch, streams and timers (c->lane2) whose read / index / probe buffers are views of this
+// one's, driven by a helper thread; while one lane sits in its chaining kernels the other runs its sort levels.
+// Results do not depend on the cut (test_internal_chunking_is_invisible); FG_LANES=1 keeps everything on one lane.
+// Measured (MI355X, gpurun_out/r03_lane_sweep*.log, r03_lanes_wl.log): D. melanogaster-like x0.5 (its chunks need several
+// sub-ranges anyway) 2185 -> 2009 ms per pass.
+static fg_ctx* laneTwo(fg_ctx* c)
+{
+	if (!c->lane2)
+	{
+		std::unique_ptr<fg_ctx> l(new fg_ctx);
+		l->device = c->device;
+		if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
+			hipStreamCreateWithFlags(&l->stream2, hipStreamNonBlocking) != hipSuccess ||
+			hipStreamCreateWithFlags(&l->stream3, hipStreamNonBlocking) != hipSuccess ||
+			hipEventCreateWithFlags(&l->evJoin3, hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&l->evOff, hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&l->evFork, hipEventDisableTiming) != hipSuccess ||
+			hipEventCreateWithFlags(&l->evJoin, hipEventDisableTiming) != hipSuccess)
+			throw FgError{FG_ERR_HIP, "streams of the second lane"};
+		for (auto& e : l->evPiece)
+			if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) throw FgError{FG_ERR_HIP, "events of the second lane"};
+		l->timer.stream = l->stream;
+		c->lane2 = std::move(l);
+	}
+	fg_ctx* l = c->lane2.get();
+	// views of everything the stage reads (refreshed per chunk: the probe buffers may have been regrown)
+	l->k = c->k; l->nReads = c->nReads; l->firstId = c->firstId; l->maxLen = c->maxLen;
+	l->totalKmers = c->totalKmers; l->totalBases = c->totalBases;
+	l->hasQ = c->hasQ; l->nQReads = c->nQReads; l->qFirstId = c->qFirstId; l->qMaxLen = c->qMaxLen;
+	l->indexBuilt = c->indexBuilt; l->sampleRate = c->sampleRate; l->nKeys = c->nKeys; l->nEntries = c->nEntries; l->nRep = c->nRep;
+	l->tableSlots = c->tableSlots; l->tableWide = c->tableWide; l->table = c->table;
+	l->timer.enabled = c->timer.enabled;
+	l->dWords.alias(c->dWords); l->dWordOff.alias(c->dWordOff); l->dLen.alias(c->dLen); l->dKmerOff.alias(c->dKmerOff);
+	l->dQWords.alias(c->dQWords); l->dQWordOff.alias(c->dQWordOff); l->dQLen.alias(c->dQLen);
+	l->dKeyOff.alias(c->dKeyOff); l->dEntries.alias(c->dEntries); l->dTable.alias(c->dTable); l->dIndexedBits.alias(c->dIndexedBits);
+	l->dQuery.alias(c->dQuery); l->dQKmerOff.alias(c->dQKmerOff); l->dProbe.alias(c->dProbe);
+	l->dCntA.alias(c->dCntA); l->dCntB.alias(c->dCntB);
+	return l;
+}
+
+// one sub-range's results, kept until the host shim runs
+struct SubResult {
+	u32 qa = 0, qb = 0;				// queries of the call
+	int lane = 0;
+	u64 lanePrimBase = 0;			// its primaries lie behind this many records of its lane's pinned buffer
+	ChunkResult cr{};
+	std::vector<u64> primOff;		// qb - qa + 1, local
+	std::vector<u64> mData, mOff;	// keep_alignment
+};
+
 void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32 nq, i32 maxOverlaps,
 				uint8_t forceLocal, fg_overlap_batch* out)
 {
 	hipStream_t s = c->stream;
 	const int k = c->k;
 	c->timer.reset();	// a call that failed half way leaves recorded events behind: back to the pool
+	c->hitCapHint = 0;
 	const auto tHost0 = std::chrono::steady_clock::now();
 	// the two bracket events come from the timer's pool and go back to it on every exit path
 	struct EvPair {
@@ -1256,50 +1318,152 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	const bool keepAln = p->keep_alignment;
 	std::vector<u64> mData, mOff(1, 0);	// keep_alignment: compacted kmerMatches per primary
 	std::vector<u64> primOffAll(nq + 1, 0);
+	std::vector<const PrimRec*> primPtr(nq, nullptr);	// primary j (counted over the call) of query qi = primPtr[qi][j]
 	std::vector<u64> hitsPerQuery;
 	u64 nPrim = 0;
 	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0;
+	const int nLanes = getenv("FG_LANES") ? std::max(1, std::min(2, atoi(getenv("FG_LANES")))) : 2;
+	const u64 laneMinHits = getenv("FG_LANE_MIN_HITS") ? strtoull(getenv("FG_LANE_MIN_HITS"), nullptr, 10) : (48ULL << 20);
+	const u32 laneSplit = getenv("FG_LANE_SPLIT") ? (u32)std::max(2, atoi(getenv("FG_LANE_SPLIT"))) : 4u;
+	bool laned = false;
+	u64 lanePrim[2] = {0, 0};		// primaries in each lane's pinned buffer so far
+	std::vector<std::unique_ptr<SubResult>> subs;
 	for (const auto& ch : chunks)
 	{
 		probeChunk(c, hq.data(), hQKmerOff.data(), ch.first, ch.second, hitsPerQuery);
-		// sub-ranges of the chunk's queries whose hits fit the budget (a single query above it is one of its own)
 		const u32 cn = ch.second - ch.first;
-		u32 sa = 0;
-		while (sa < cn)
+		u64 chunkHits = 0;
+		for (u32 i = 0; i < cn; ++i) chunkHits += hitsPerQuery[i];
+		// sub-ranges of the chunk's queries whose hits fit the budget (a single query above it is one of its own);
+		// with two lanes a chunk of enough hits is cut into at least laneSplit of them
+		// Two lanes where the chunk has to be cut anyway (its hits exceed the budget: then each lane takes pieces of half
+		// the budget).  Cutting a chunk that fits only to have two lanes pays on some workloads and costs on others
+		// (every piece ends on the long waves of its chaining kernels): E. coli PB 50x 55.9 -> 53.9 ms in two halves,
+		// 64 ms in four; HiFi parameters 265 -> 289 ms -- so that is left to FG_LANE_MIN_HITS (experiments).
+		const bool forcedCut = getenv("FG_LANE_MIN_HITS") && chunkHits >= laneMinHits && cn >= 2 * laneSplit;
+		const bool twoLanes = nLanes == 2 && (chunkHits > hitBudget || forcedCut);
+		const u64 budget = !twoLanes ? hitBudget
+			: (chunkHits > hitBudget ? std::max<u64>(1, hitBudget / 2) : std::max<u64>(1, (chunkHits + laneSplit - 1) / laneSplit));
+		std::vector<std::pair<u32, u32>> ranges;
+		u64 maxSubHits = 0;
+		// experiment: FG_LANE_FRACS="25,50,25" cuts the chunk at those shares of its hits (uneven pieces put the two
+		// lanes out of phase: one in its sort levels while the other is in its chaining kernels)
+		std::vector<u64> cuts;
+		if (twoLanes && getenv("FG_LANE_FRACS") && chunkHits / 2 <= hitBudget)
+		{
+			u64 accPct = 0;
+			for (const char* q = getenv("FG_LANE_FRACS"); *q;)
+			{
+				accPct += strtoull(q, (char**)&q, 10);
+				if (*q == ',') ++q;
+				cuts.push_back(chunkHits / 100 * std::min<u64>(accPct, 100));
+			}
+		}
+		size_t cutI = 0;
+		u64 before = 0;
+		for (u32 sa = 0; sa < cn;)
 		{
 			u32 sb = sa + 1;
 			u64 acc = hitsPerQuery[sa];
-			while (sb < cn && acc + hitsPerQuery[sb] <= hitBudget) acc += hitsPerQuery[sb++];
-			const u32 qa = ch.first + sa, qb = ch.first + sb;
-			ChunkResult cr;
-			deviceSub(c, p, forceLocal, sa, sb - sa, nPrim, &cr);
-			out->seed_hits += cr.nHits; out->dp_groups += cr.dpGroups; out->dp_elements += cr.dpElems;
-			const u64* off = c->hOff.p;
-			for (u32 i = 0; i < qb - qa; ++i) primOffAll[qa + i + 1] = nPrim + off[i + 1];
-			if (keepAln)
+			if (!cuts.empty())
 			{
-				mData.reserve(mData.size() + cr.nMatchSlots);
-				for (u64 j = 0; j < cr.nPrim; ++j)
-				{
-					const u64 slotEnd = c->hMatchOff.p[j + 1];
-					const u32 cnt = c->hMatchCnt.p[j];
-					mData.insert(mData.end(), c->hMatches.p + slotEnd - cnt, c->hMatches.p + slotEnd);
-					mOff.push_back(mData.size());
-				}
+				const u64 upTo = cutI + 1 < cuts.size() ? cuts[cutI] : chunkHits;
+				while (sb < cn && before + acc + hitsPerQuery[sb] <= upTo) acc += hitsPerQuery[sb++];
+				if (cutI + 1 >= cuts.size()) { while (sb < cn) acc += hitsPerQuery[sb++]; }
+				++cutI;
 			}
-			nPrim += cr.nPrim;
+			else
+				while (sb < cn && acc + hitsPerQuery[sb] <= budget) acc += hitsPerQuery[sb++];
+			ranges.push_back({sa, sb});
+			maxSubHits = std::max(maxSubHits, acc);
+			before += acc;
 			sa = sb;
 		}
+		const size_t sub0Index = subs.size();
+		for (auto& r : ranges)
+		{
+			subs.emplace_back(new SubResult);
+			subs.back()->qa = ch.first + r.first; subs.back()->qb = ch.first + r.second;
+		}
+		fg_ctx* lanes[2] = {c, nullptr};
+		const bool useTwo = twoLanes && ranges.size() >= 2;
+		if (useTwo) { lanes[1] = laneTwo(c); if (!laned) lanes[1]->timer.reset(); laned = true; }
+		std::atomic<size_t> next{0};
+		std::exception_ptr laneErr[2];
+		auto work = [&](int lane)
+		{
+			try
+			{
+				fg_ctx* lc = lanes[lane];
+				(void)hipSetDevice(lc->device);
+				while (true)
+				{
+					const size_t i = next.fetch_add(1);
+					if (i >= ranges.size()) break;
+					SubResult& sr = *subs[sub0Index + i];
+					sr.lane = lane;
+					sr.lanePrimBase = lanePrim[lane];
+					deviceSub(lc, p, forceLocal, ranges[i].first, ranges[i].second - ranges[i].first, lanePrim[lane], maxSubHits, &sr.cr);
+					const u32 n = ranges[i].second - ranges[i].first;
+					sr.primOff.assign(lc->hOff.p, lc->hOff.p + n + 1);
+					if (keepAln)
+					{
+						sr.mOff.assign(1, 0);
+						sr.mData.reserve(sr.cr.nMatchSlots);
+						for (u64 j = 0; j < sr.cr.nPrim; ++j)
+						{
+							const u64 slotEnd = lc->hMatchOff.p[j + 1];
+							const u32 cnt = lc->hMatchCnt.p[j];
+							sr.mData.insert(sr.mData.end(), lc->hMatches.p + slotEnd - cnt, lc->hMatches.p + slotEnd);
+							sr.mOff.push_back(sr.mData.size());
+						}
+					}
+					lanePrim[lane] += sr.cr.nPrim;
+				}
+				if (useTwo) HIP_CHECK(hipStreamSynchronize(lc->stream));	// the next chunk's probes overwrite what the sub-ranges read
+			}
+			catch (...) { laneErr[lane] = std::current_exception(); }
+		};
+		if (useTwo)
+		{
+			std::thread helper(work, 1);
+			work(0);
+			helper.join();
+		}
+		else work(0);
+		for (int l = 0; l < 2; ++l) if (laneErr[l]) std::rethrow_exception(laneErr[l]);
+	}
+	// the sub-ranges in query order: offsets over the whole call, where each query's primaries lie
+	for (auto& srp : subs)
+	{
+		SubResult& sr = *srp;
+		fg_ctx* lc = sr.lane ? c->lane2.get() : c;
+		const PrimRec* base = (const PrimRec*)lc->hPrim.p + sr.lanePrimBase;
+		for (u32 i = 0; i < sr.qb - sr.qa; ++i)
+		{
+			primOffAll[sr.qa + i + 1] = nPrim + sr.primOff[i + 1];
+			primPtr[sr.qa + i] = base - nPrim;
+		}
+		if (keepAln)
+			for (u64 j = 0; j < sr.cr.nPrim; ++j)
+			{
+				mData.insert(mData.end(), sr.mData.begin() + sr.mOff[j], sr.mData.begin() + sr.mOff[j + 1]);
+				mOff.push_back(mData.size());
+			}
+		out->seed_hits += sr.cr.nHits; out->dp_groups += sr.cr.dpGroups; out->dp_elements += sr.cr.dpElems;
+		nPrim += sr.cr.nPrim;
 	}
 	HIP_CHECK(hipEventRecord(evB, s));
-	// no wait for the last chunk's records here: piece by piece in the shim's first pass
-	const PrimRec* hPrim = (const PrimRec*)c->hPrim.p;
+	// no wait for the last chunk's records here: piece by piece in the shim's first pass (one lane; with two, both
+	// lanes' copies have been waited for above)
 	const u64* hPrimOff = primOffAll.data();
 	const auto tHost1 = std::chrono::steady_clock::now();
 	const int dev = c->device;
 	std::atomic<int> waitErr{0};		// worker threads must not throw
-	auto waitPrim = [c, dev, &waitErr](u64 endIdx)
+	const bool pieceWait = !laned && subs.size() <= 1;
+	auto waitPrim = [c, dev, &waitErr, pieceWait](u64 endIdx)
 	{
+		if (!pieceWait) return;
 		// primaries below endIdx are on the host when the first piece reaching that far has landed (copies of one
 		// stream complete in order; earlier chunks' pieces lie below this chunk's first)
 		(void)hipSetDevice(dev);
@@ -1350,6 +1514,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			size_t detected = 0;
 			u32 prevExt = 0xFFFFFFFFu;
 			if (keepAln) nMatch[qi] = 0;
+			const PrimRec* hPrim = primPtr[qi];
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
 				const PrimRec& r = hPrim[j];
@@ -1387,6 +1552,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 		}
 	};
 	auto runThreads = [&](const std::function<void(unsigned)>& fn) { c->shimPool.run(nThreads, fn); };
+	if (!pieceWait) HIP_CHECK(hipStreamSynchronize(s));		// several sub-ranges: their copies are simply waited for
 	runThreads(pass1);
 	HIP_CHECK(hipStreamSynchronize(s));		// everything has landed by now; also surfaces a failed copy
 	if (waitErr.load()) throw FgError{FG_ERR_HIP, std::string("waiting for the result copy: ") + hipGetErrorString((hipError_t)waitErr.load())};
@@ -1419,6 +1585,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 			const i32 curLen = (c->hasQ ? c->hQLen : c->hLen)[hq[qi] >> 1];
 			fg_overlap_rec* dst = own->recs + own->queryOff[qi];
 			u64 mo = keepAln ? qMatchOff[qi] : 0;
+			const PrimRec* hPrim = primPtr[qi];
 			for (u64 j = hPrimOff[qi]; j < hPrimOff[qi + 1]; ++j)
 			{
 				if (!keep[j]) continue;
@@ -1466,8 +1633,20 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	}
 	float ms = 0;
 	HIP_CHECK(hipEventElapsedTime(&ms, evA, evB));
-	out->device_seconds = ms * 1e-3;
+	out->device_seconds = laned ? std::chrono::duration<double>(tHost1 - tHost0).count() : ms * 1e-3;
 	c->timer.collect();
+	if (laned && c->lane2)
+	{
+		// the second lane's kernel times, name by name
+		c->lane2->timer.collect();
+		for (const auto& kt : c->lane2->timer.last)
+		{
+			bool found = false;
+			for (auto& mine : c->timer.last)
+				if (!strcmp(mine.name, kt.name)) { mine.seconds += kt.seconds; mine.launches += kt.launches; found = true; break; }
+			if (!found) c->timer.last.push_back(kt);
+		}
+	}
 	const auto tHost2 = std::chrono::steady_clock::now();
 	c->timer.last.push_back(fg_kernel_time{"host:launch+sync (wall, includes the device time)",
 							std::chrono::duration<double>(tHost1 - tHost0).count(), 1});

@@ -925,3 +925,43 @@ def test_bridge_bulk_mode_for_unpredictable_walks(built):
     assert s["device_calls"] < 0.1 * s["requests"], s
     oc.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["raw_pb", "hifi", "repeat_raw"])
+def test_two_lanes_are_invisible(built, golden_cases, monkeypatch, name):
+    """Sub-ranges of a call's queries run on two lanes side by side (a second set of scratch, streams and a helper
+    thread, fg_overlap.hip) when a chunk's hits exceed the budget; forced here at golden-case size -- tiny budgets, so
+    that both the budget-driven cut and the forced one are taken: same records, same order, kmerMatches included."""
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    from flye_amd import config
+    cfg = config.preset(case["preset"])
+    from flye_amd import gpu
+    if name.startswith("repeat"):
+        from helpers import repeat_stage_setup
+        wnd, dk = repeat_stage_setup(case, cfg)
+        ctx = gpu.Context(int(cfg["kmer_size"]), 0)
+        ctx.set_reads(rs, 0)
+        vi = gpu.VertexIndex(ctx, float(int(cfg["assemble_kmer_sample"])))
+        vi.buildIndexMinimizers(1, wnd, cfg["repeat_kmer_rate"])
+        det = gpu.OverlapDetector(ctx, vi, int(cfg["maximum_jump"]), dk["min_overlap"], dk["max_overhang"], True,
+                                  dk["only_max_ext"], dk["max_divergence"], dk["nucl_alignment"], True,
+                                  bool(cfg["hpc_scoring_on"]))
+    else:
+        ctx, vi, st, det = _gpu_setup(rs, cfg)
+        det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    q = np.arange(0, 2 * rs.n, dtype=np.uint32) if name.startswith("repeat") else case_queries(case, rs.n)
+    one = det.getSeqOverlapsBatch(q, forceLocal=case.get("force_local", False), maxOverlaps=case.get("max_overlaps", 0))
+    for env in ({"FG_HIT_BUDGET": "20000", "FG_KMER_BUDGET": str(1 << 30)}, {"FG_LANE_MIN_HITS": "1000", "FG_LANE_SPLIT": "3"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        two = det.getSeqOverlapsBatch(q, forceLocal=case.get("force_local", False), maxOverlaps=case.get("max_overlaps", 0))
+        assert two.recs.tobytes() == one.recs.tobytes() and np.array_equal(two.query_off, one.query_off)
+        if det.p.keep_alignment:
+            assert np.array_equal(two.match_off, one.match_off) and np.array_equal(two.matches, one.matches)
+            assert np.array_equal(two.needs_trim, one.needs_trim)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    if not name.startswith("repeat"):
+        assert one.lines() == golden_lines(name)
+    ctx.close()
