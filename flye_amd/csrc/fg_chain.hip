@@ -111,11 +111,12 @@ __device__ __forceinline__ void append2_multi(const bool (&a)[LIST_ITEMS], const
 // 244-249 would drop the group anyway, here it never costs k_group_prep a wave)
 __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ groupStart, u32 minSize,
 							 const u32* __restrict__ groupFirstCur, const u32* __restrict__ groupLastCur, i32 minOverlap,
-							 u32* __restrict__ list, u32* __restrict__ listBig, u32 bigMin, u32* __restrict__ counts,
+							 u32* __restrict__ list, u32* __restrict__ listBig, u32 bigMin,
+							 u32* __restrict__ listFused, u32 fusedMax /* 0: no fused class */, u32* __restrict__ counts,
 							 u32* __restrict__ primCount, u32* __restrict__ dpSize)
 {
 	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
-	bool a[LIST_ITEMS], b[LIST_ITEMS];
+	bool a[LIST_ITEMS], b[LIST_ITEMS], f[LIST_ITEMS], none[LIST_ITEMS];
 	u64 start = g0 < nGroups ? groupStart[g0] : nHits;
 #pragma unroll
 	for (int t = 0; t < LIST_ITEMS; ++t)
@@ -133,10 +134,17 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 				ok = (i32)groupLastCur[g] - (i32)groupFirstCur[g] >= minOverlap;
 			start = gend;
 		}
-		a[t] = ok && n <= bigMin;
+		f[t] = ok && n <= fusedMax;				// the whole chaining stage in one kernel (k_chain_small)
+		a[t] = ok && n > fusedMax && n <= bigMin;
 		b[t] = ok && n > bigMin;	// groups that k_group_prep handles in global memory
+		none[t] = false;
 	}
 	append2_multi(a, b, (u32)g0, list, listBig, counts);
+	if (fusedMax)
+	{
+		__syncthreads();	// the helper's shared counters are reused
+		append2_multi(f, none, (u32)g0, listFused, listFused, counts + 2);
+	}
 }
 
 #ifndef FIN_CAP_S
@@ -159,8 +167,8 @@ __global__ void k_group_list(u64 nGroups, u64 nHits, const u64* __restrict__ gro
 // 7.0 / 6.2 / 6.1 / 6.4 / 8.0 ms against 7.8 ms with the walk in global memory; staging the SORT
 // of 257..1024-hit groups in LDS as well costs more occupancy than it saves latency.)
 // groups that passed the prefilter, by size class
-__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32 hugeMin, u32* __restrict__ listSmall,
-						  u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
+__global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32 hugeMin, u32 doneMax /* groups up to this size are finished already */,
+						  u32* __restrict__ listSmall, u32* __restrict__ listMid, u32* __restrict__ listBig, u32* __restrict__ counts)
 {
 	const u64 g0 = ((u64)blockIdx.x * WG + threadIdx.x) * LIST_ITEMS;
 	bool a[LIST_ITEMS], b[LIST_ITEMS], h[LIST_ITEMS], none[LIST_ITEMS];
@@ -168,8 +176,8 @@ __global__ void k_dp_list(u64 nGroups, const u32* __restrict__ dpSize, u32 hugeM
 	for (int t = 0; t < LIST_ITEMS; ++t)
 	{
 		const u32 n = g0 + t < nGroups ? dpSize[g0 + t] : 0u;
-		a[t] = n > 0 && n <= FIN_CAP_S;
-		b[t] = n > FIN_CAP_S && n <= hugeMin;
+		a[t] = n > doneMax && n <= FIN_CAP_S;
+		b[t] = n > FIN_CAP_S && n > doneMax && n <= hugeMin;
 		h[t] = n > hugeMin;
 		none[t] = false;
 	}
@@ -359,9 +367,10 @@ __device__ __forceinline__ u32 abs_diff(i32 a, i32 b)
 	return r;
 }
 
-template <bool EXTS>
+// WHOLE: the whole group (<= DP_RING hits) sits in LDS arrays cur / ext / score: deep look-backs read those, no ring
+template <bool EXTS, bool WHOLE = false>
 __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i32 n, const u32* __restrict__ cur,
-										 const u32* __restrict__ ext, i32* __restrict__ score, i32* __restrict__ back,
+										 const u32* __restrict__ ext, i32* score, i32* __restrict__ back,
 										 i32* ringC, i32* ringE, i32* ringS)
 {
 	const int lane = threadIdx.x & 63;
@@ -438,7 +447,8 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 				i32 cp = FAR, ep = FAR, sj = 0;
 				if (j >= 0)
 				{
-					if (j >= tb0 - DP_RING)
+					if (WHOLE) { cp = (i32)cur[j]; ep = (i32)ext[j]; sj = score[j]; }
+					else if (j >= tb0 - DP_RING)
 					{
 						cp = ringC[j & (DP_RING - 1)]; ep = ringE[j & (DP_RING - 1)]; sj = ringS[j & (DP_RING - 1)];
 					}
@@ -472,8 +482,9 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 		if (valid)
 		{
 			score[tb0 + lane] = ts; back[tb0 + lane] = tbk;
-			ringC[(tb0 + lane) & (DP_RING - 1)] = tc; ringE[(tb0 + lane) & (DP_RING - 1)] = te; ringS[(tb0 + lane) & (DP_RING - 1)] = ts;
+			if (!WHOLE) { ringC[(tb0 + lane) & (DP_RING - 1)] = tc; ringE[(tb0 + lane) & (DP_RING - 1)] = te; ringS[(tb0 + lane) & (DP_RING - 1)] = ts; }
 		}
+		if (WHOLE) wsort::wave_mem_fence();		// the next tile's deep look-backs read these scores from LDS
 		pc = tc; pe = te; ps = ts;
 	}
 }
@@ -502,65 +513,31 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 }
 
 // ---- finish ------------------------------------------------------------------------------
-// CAP = 0: everything in global scratch; otherwise the group (<= CAP hits) is staged in LDS
-// BT_CAP > 0 (CAP = 0 only): groups of <= BT_CAP hits walk their back pointers in LDS
-template <int CAP, int FIN_WAVES, int BT_CAP = 0>
-__global__ void __launch_bounds__(FIN_WAVES * 64)
-k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
-			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
-			   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
-			   const u32* __restrict__ groupExt,
-			   const u32* __restrict__ gCur, const u32* __restrict__ gExt, i32* __restrict__ gScore,
-			   i32* __restrict__ gBack, u32* __restrict__ gAux /* 4 u32 per hit */, int4* __restrict__ cand,
-			   u32* __restrict__ primCount)
+// One group's backtracking stage on one wave (the body of k_chain_finish and of the fused small-group kernel):
+// score / back: the DP's arrays (LDS when USE_LDS, else the group's global ones; back is consumed), okey / oval:
+// n u32 each for the score order, pl / pr: the sort's position lists (u16 in LDS, else u32 behind oval), btLds: LDS
+// copy of the back pointers for the walk (BT_CAP > 0 only).
+template <bool USE_LDS, int BT_CAP>
+__device__ __forceinline__ void finish_group(const ChainParams& P, const i32 n, const u32 curId, const u32 extId, const i32 curLen,
+											 const i32 extLen, const u32* cur, const u32* ext, i32* score, i32* back, u32* okey, u32* oval,
+											 unsigned short* plLds, int* stack, int* small, i32* btLds, int4* cd, u32* primCountG)
 {
-	constexpr bool USE_LDS = CAP > 0;
-	// dynamic LDS: per wave CAP * 20 bytes (score, back, order key, order value, 2 x u16 scratch)
-	extern __shared__ __attribute__((aligned(16))) char finLds[];
-	__shared__ int stack[FIN_WAVES][3 * 40];
-	__shared__ int small[FIN_WAVES][3 * 8];
-	__shared__ i32 btLds[FIN_WAVES][BT_CAP > 0 ? BT_CAP : 1];
-	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	const u32 li = blockIdx.x * FIN_WAVES + wv;
-	if (li >= nList) return;
-	const u64 g = fg_uni(list[li]);
-	const u64 g0 = fg_uni(groupStart[g]);
-	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
-	const i32 n = (i32)(gend - g0);
-	const u32 q = groupQuery[g];
 	const int k = P.k;
-	const u32* cur = gCur + g0;
-	const u32* ext = gExt + g0;
-	i32 *score, *back; u32 *okey, *oval;
-	if (USE_LDS)
-	{
-		char* base = finLds + (size_t)wv * CAP * 20;
-		score = (i32*)base; back = score + CAP; okey = (u32*)(back + CAP); oval = okey + CAP;
-		for (i32 i = lane; i < n; i += 64) { score[i] = gScore[g0 + i]; back[i] = gBack[g0 + i]; }
-		wsort::wave_mem_fence();
-	}
-	else
-	{
-		score = gScore + g0; back = gBack + g0; okey = gAux + 4 * g0; oval = okey + n;
-	}
 	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
 	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
 	wsort::wave_mem_fence();
 	if (!(P.ablate & 2))
 	{
 		if (USE_LDS)
-		{
-			unsigned short* pl = (unsigned short*)(oval + CAP);
-			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + CAP, stack[wv], small[wv]);
-		}
+			wsort::wave_sort<u32, unsigned short>(okey, oval, n, plLds, plLds + n, stack, small);
 		else if (BT_CAP > 0 && n <= BT_CAP)
 		{
 			// the walk's LDS (4 B per hit) first serves as the sort's two position lists
-			unsigned short* pl = (unsigned short*)btLds[wv];
-			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + BT_CAP, stack[wv], small[wv]);
+			unsigned short* pl = (unsigned short*)btLds;
+			wsort::wave_sort<u32, unsigned short>(okey, oval, n, pl, pl + BT_CAP, stack, small);
 		}
-		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack[wv], small[wv]);
+		else wsort::wave_sort<u32, u32>(okey, oval, n, oval + n, oval + 2 * n, stack, small);
 	}
 
 	if (P.ablate & 8) return;
@@ -574,19 +551,13 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	if (BT_CAP > 0 && n <= BT_CAP)
 	{
 		// the serial pointer chase below is latency bound: keep the back pointers in LDS
-		for (i32 i = lane; i < n; i += 64) btLds[wv][i] = back[i];
-		back = btLds[wv];
+		for (i32 i = lane; i < n; i += 64) btLds[i] = back[i];
+		back = btLds;
 	}
 	// backtracking with consumption, overlapTest, primary selection.  Consumption only ever
 	// turns back[] entries into -1, so a start whose entry already is -1 can be skipped for good:
 	// the wave screens 64 order entries at once and lane 0 walks only the survivors (re-checking
 	// each, since a chain walked in between may have consumed it).
-	const u32 qrec = query[q];
-	const u32 curId = P.qFirstId + qrec;
-	const u32 extId = groupExt[g];
-	const i32 curLen = qLen[qrec >> 1];
-	const i32 extLen = len[(extId - P.firstId) >> 1];
-	int4* cd = cand + g0;
 	i32 ncand = 0;
 	int4 best = make_int4(0, 0, 0, 0);
 	wsort::wave_mem_fence();
@@ -710,13 +681,13 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 	if (ncand > 16)
 	{
 		CandAcc acc{cd};
-		fgsort::sort(acc, 0, ncand, stack[wv]);	// 3*40 ints >= fgsort::STACK_INTS
+		fgsort::sort(acc, 0, ncand, stack);	// 3*40 ints >= fgsort::STACK_INTS
 		best = cd[0];
 	}
 	if (P.onlyMaxExt)
 	{
 		cd[0] = best;
-		primCount[g] = 1;
+		*primCountG = 1;
 		return;
 	}
 	if (ncand <= 16)
@@ -742,7 +713,138 @@ k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGrou
 		}
 		if (!contained) cd[nprim++] = o;	// nprim <= a: never overwrites an unread candidate
 	}
-	primCount[g] = (u32)nprim;
+	*primCountG = (u32)nprim;
+}
+
+
+// CAP = 0: everything in global scratch; otherwise the group (<= CAP hits) is staged in LDS
+// BT_CAP > 0 (CAP = 0 only): groups of <= BT_CAP hits walk their back pointers in LDS
+template <int CAP, int FIN_WAVES, int BT_CAP = 0>
+__global__ void __launch_bounds__(FIN_WAVES * 64)
+k_chain_finish(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+			   const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+			   const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
+			   const u32* __restrict__ groupExt,
+			   const u32* __restrict__ gCur, const u32* __restrict__ gExt, i32* __restrict__ gScore,
+			   i32* __restrict__ gBack, u32* __restrict__ gAux /* 4 u32 per hit */, int4* __restrict__ cand,
+			   u32* __restrict__ primCount)
+{
+	constexpr bool USE_LDS = CAP > 0;
+	// dynamic LDS: per wave CAP * 20 bytes (score, back, order key, order value, 2 x u16 scratch)
+	extern __shared__ __attribute__((aligned(16))) char finLds[];
+	__shared__ int stack[FIN_WAVES][3 * 40];
+	__shared__ int small[FIN_WAVES][3 * 8];
+	__shared__ i32 btLds[FIN_WAVES][BT_CAP > 0 ? BT_CAP : 1];
+	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	const u32 li = blockIdx.x * FIN_WAVES + wv;
+	if (li >= nList) return;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u32 q = groupQuery[g];
+	const u32* cur = gCur + g0;
+	const u32* ext = gExt + g0;
+	i32 *score, *back; u32 *okey, *oval;
+	unsigned short* plLds = nullptr;
+	if (USE_LDS)
+	{
+		char* base = finLds + (size_t)wv * CAP * 20;
+		score = (i32*)base; back = score + CAP; okey = (u32*)(back + CAP); oval = okey + CAP;
+		plLds = (unsigned short*)(oval + CAP);
+		for (i32 i = lane; i < n; i += 64) { score[i] = gScore[g0 + i]; back[i] = gBack[g0 + i]; }
+		wsort::wave_mem_fence();
+	}
+	else
+	{
+		score = gScore + g0; back = gBack + g0; okey = gAux + 4 * g0; oval = okey + n;
+	}
+	const u32 qrec = query[q];
+	const u32 extId = groupExt[g];
+	finish_group<USE_LDS, BT_CAP>(P, n, P.qFirstId + qrec, extId, qLen[qrec >> 1], len[(extId - P.firstId) >> 1], cur, ext, score, back,
+								  okey, oval, plLds, stack[wv], small[wv], btLds[wv], cand + g0, primCount + g);
+}
+
+// ---- the whole chaining stage of a small group in ONE kernel -----------------------------------------------------
+// Groups of <= FIN_CAP_S hits (nine in ten of the groups that reach the DP on raw reads) go through prefilter, optional
+// re-sort, DP, score-order sort, backtracking and primary selection on one wave without leaving LDS: what
+// k_group_prep, k_chain_dp and k_chain_finish<lds256> did in three launches, handing (cur, ext) and (score, back)
+// to one another through global memory.  Only what later kernels read is written out: the (cur, ext) columns in DP
+// order (k_prim_gather, k_chain_matches), the back pointers when kmerMatches are wanted, the candidates.
+template <class KT>
+__global__ void __launch_bounds__(64)
+k_chain_small(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, u64 nHits,
+			  const u64* __restrict__ groupStart, const u32* __restrict__ groupQuery,
+			  const u32* __restrict__ query, const i32* __restrict__ len, const i32* __restrict__ qLen,
+			  HitKeyView<KT> hitKey, const u32* __restrict__ groupExt,
+			  u32* __restrict__ gCur, u32* __restrict__ gExt, i32* __restrict__ gBack, int4* __restrict__ cand,
+			  u32* __restrict__ dpSize, u32* __restrict__ primCount, int cap /* largest group: 28 B of LDS per hit */)
+{
+	extern __shared__ __attribute__((aligned(16))) char smallLds[];
+	u32* const sCur = (u32*)smallLds; u32* const sExt = sCur + cap;
+	i32* const sScore = (i32*)(sExt + cap); i32* const sBack = sScore + cap;
+	u32* const sOkey = (u32*)(sBack + cap); u32* const sOval = sOkey + cap;
+	unsigned short* const sP = (unsigned short*)(sOval + cap);
+	__shared__ int stack[3 * 40];
+	__shared__ int small[3 * 8];
+	const int lane = threadIdx.x;
+	const u32 li = blockIdx.x;
+	if (li >= nList) return;
+	const u64 g = fg_uni(list[li]);
+	const u64 g0 = fg_uni(groupStart[g]);
+	const u64 gend = (g + 1 < nGroups) ? fg_uni(groupStart[g + 1]) : nHits;
+	const i32 n = (i32)(gend - g0);
+	const u32 qrec = query[groupQuery[g]];
+	const u32 extId = groupExt[g];
+	const i32 curLen = qLen[qrec >> 1];
+	const i32 extLen = len[(extId - P.firstId) >> 1];
+	const i32 minCur = (i32)hitKey.cur(g0), maxCur = (i32)hitKey.cur(g0 + n - 1);
+	// distinct query positions (overlap.cpp:220-235; prevPos starts at 0), ext span; the hits are staged on the way
+	u32 uniq = 0;
+	i32 minExt = 0x7fffffff, maxExt = I32_MIN;
+	for (i32 i = lane; i < n; i += 64)
+	{
+		const u32 c = hitKey.cur(g0 + i);
+		const u32 pc = i ? hitKey.cur(g0 + i - 1) : 0u;
+		uniq += (c != pc);
+		const i32 e = (i32)hitKey.val(g0 + i);
+		minExt = min(minExt, e); maxExt = max(maxExt, e);
+		sCur[i] = c; sExt[i] = (u32)e;
+	}
+	for (int o = 32; o > 0; o >>= 1)
+	{
+		uniq += __shfl_xor(uniq, o);
+		minExt = min(minExt, __shfl_xor(minExt, o));
+		maxExt = max(maxExt, __shfl_xor(maxExt, o));
+	}
+	if ((float)uniq < P.minUnique) return;
+	if (maxCur - minCur < P.minOverlap || maxExt - minExt < P.minOverlap) return;
+	if (P.checkOverhang && !P.forceLocal)
+	{
+		if (min(minCur, minExt) > P.maxOverhang) return;
+		if (min(curLen - maxCur, extLen - maxExt) > P.maxOverhang) return;
+	}
+	if (lane == 0) dpSize[g] = (u32)n;
+	const bool extSorted = extLen > curLen;
+	wsort::wave_mem_fence();
+	if (extSorted)
+	{
+		// (strictly ascending target positions need no re-sort: see k_group_prep)
+		bool asc = true;
+		for (i32 i = lane + 1; i < n; i += 64) asc = asc && sExt[i] > sExt[i - 1];
+		if (__builtin_amdgcn_ballot_w64(!asc))
+			wsort::wave_sort<u32, unsigned short>(sExt, sCur, n, sP, sP + n, stack, small);
+	}
+	for (i32 i = lane; i < n; i += 64) { gCur[g0 + i] = sCur[i]; gExt[g0 + i] = sExt[i]; }
+	wsort::wave_mem_fence();
+	if (extSorted) dp_group<true, true>(P.k, P.maxJump, n, sCur, sExt, sScore, sBack, nullptr, nullptr, nullptr);
+	else dp_group<false, true>(P.k, P.maxJump, n, sCur, sExt, sScore, sBack, nullptr, nullptr, nullptr);
+	wsort::wave_mem_fence();
+	if (P.keepAln)
+		for (i32 i = lane; i < n; i += 64) gBack[g0 + i] = sBack[i];	// k_chain_matches walks them again; the copy in LDS is consumed
+	finish_group<true, 0>(P, n, P.qFirstId + qrec, extId, curLen, extLen, sCur, sExt, sScore, sBack, sOkey, sOval, sP, stack, small,
+						  nullptr, cand + g0, primCount + g);
 }
 
 u32 fetchU32(fg_ctx* c, const u32* dptr)
@@ -788,17 +890,130 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	c->dTmp32.reserve(4 * hitCap + 16);
 	c->dCand.reserve(hitCap + 1);
 	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
+	// groups of <= FIN_CAP_S hits take the one-kernel path (k_chain_small); FG_CHAIN_FUSED=0: the three-kernel path for all
+	const bool fused = !(getenv("FG_CHAIN_FUSED") && atoi(getenv("FG_CHAIN_FUSED")) == 0);
+	// (its LDS: 28 B per hit of the largest group it takes; FG_FUSED_CAP for experiments)
+	const u32 fusedMax = fused ? (getenv("FG_FUSED_CAP") ? (u32)std::max(64, std::min(1024, atoi(getenv("FG_FUSED_CAP")))) : (u32)FIN_CAP_S) : 0u;
+	if (fused) c->dListFused.reserve(nGroups + 1);
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");
 	  hipLaunchKernelGGL(k_group_list, gridG, WG, 0, s, nGroups, nHits, c->dGroupStart.p, minSize, c->dGroupFirstCur.p,
 						 c->dGroupLastCur.p, (i32)p->min_overlap, c->dListSmall.p, c->dListBig.p, (u32)PREP_CAP,
-						 c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
-	u32 nPrep[2];
+						 c->dListFused.p, fusedMax, c->dListCnt.p, c->dPrimFlag.p, c->dDpSize.p); }
+	u32 nPrep[4];
 	c->hScalar.reserve(8);
-	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 8, hipMemcpyDeviceToHost, s));
+	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	memcpy(nPrep, c->hScalar.p, 8);
-	if (!nPrep[0] && !nPrep[1]) return;
+	memcpy(nPrep, c->hScalar.p, 16);
+	const u32 nFused = fused ? nPrep[2] : 0u;
+	if (!nPrep[0] && !nPrep[1] && !nFused) return;
+	if (fused)
+	{
+		// Main stream: the small groups, start to end in one kernel.  Beside it on the side streams: the larger groups'
+		// prefilter (stream 2), their size classes listed, then the two classes' DP -> finish chains (streams 2 and 3).
+		const bool others = nPrep[0] || nPrep[1];
+		const bool sideStreams = !(getenv("FG_CHAIN_STREAMS") && atoi(getenv("FG_CHAIN_STREAMS")) == 1);	// 1: everything on the main stream
+		if (others && sideStreams)
+		{
+			HIP_CHECK(hipEventRecord(c->evFork, s));
+			HIP_CHECK(hipStreamWaitEvent(c->stream2, c->evFork, 0));
+		}
+		if (nFused)
+		{
+			ScopedK t(c->timer, "k_chain_small");
+#define SMALL_ARGS(view) cp, c->dListFused.p, nFused, nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, qLen, \
+			view, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dBack.p, c->dCand.p, c->dDpSize.p, c->dPrimFlag.p, (int)fusedMax
+			const size_t ldsSmall = (size_t)fusedMax * 28;
+			if (keyMode == 0)
+				hipLaunchKernelGGL(k_chain_small<u32>, nFused, 64, ldsSmall, s, SMALL_ARGS((HitKeyView<u32>{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId})));
+			else if (keyMode == 1)
+				hipLaunchKernelGGL(k_chain_small<PK>, nFused, 64, ldsSmall, s, SMALL_ARGS((HitKeyView<PK>{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId})));
+			else
+				hipLaunchKernelGGL(k_chain_small<u64>, nFused, 64, ldsSmall, s, SMALL_ARGS((HitKeyView<u64>{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId})));
+#undef SMALL_ARGS
+		}
+		if (!others) return;
+		hipStream_t s2 = sideStreams ? c->stream2 : s, s3 = sideStreams ? c->stream3 : s;
+		const u32* prepList[2] = {c->dListSmall.p, c->dListBig.p};
+#define PREP_ARGS(view, cls) cp, prepList[cls], nPrep[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, qLen, \
+		view, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dTmp32.p, c->dDpSize.p, c->dGroupExtSorted.p
+		for (int cls = 1; cls >= 0; --cls)
+		{
+			if (!nPrep[cls]) continue;
+			ScopedK t(c->timer, "k_group_prep", s2);
+			const unsigned gridP = (nPrep[cls] + PREP_WAVES - 1) / PREP_WAVES;
+			if (keyMode == 0)
+				hipLaunchKernelGGL(k_group_prep<u32>, gridP, PREP_WAVES * 64, 0, s2,
+								   PREP_ARGS((HitKeyView<u32>{c->dHitKey32.p, c->dHitVal.p, curBits, c->firstId}), cls));
+			else if (keyMode == 1)
+				hipLaunchKernelGGL(k_group_prep<PK>, gridP, PREP_WAVES * 64, 0, s2,
+								   PREP_ARGS((HitKeyView<PK>{(const PK*)c->dHitKey.p, nullptr, curBits, c->firstId}), cls));
+			else
+				hipLaunchKernelGGL(k_group_prep<u64>, gridP, PREP_WAVES * 64, 0, s2,
+								   PREP_ARGS((HitKeyView<u64>{c->dHitKey.p, c->dHitVal.p, curBits, c->firstId}), cls));
+		}
+#undef PREP_ARGS
+		// (the group lists of k_group_list are dead once the preps have run: dListSmall is reused for the empty small class)
+		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s2));
+		const bool smallCall2 = (nPrep[0] + nPrep[1] + nFused) < 65536u && !getenv("FG_CHAIN_NO_SMALL_CALL");
+		const u32 hugeMin2 = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : (smallCall2 ? (u32)FIN_CAP_M : 4096u);
+		{ ScopedK t(c->timer, "k_dp_list", s2);
+		  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s2, nGroups, c->dDpSize.p, hugeMin2, fusedMax, c->dListSmall.p, c->dListDp.p,
+							 c->dListBig.p, c->dListCnt.p); }
+		u32 hc2[4];
+		HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s2));
+		HIP_CHECK(hipStreamSynchronize(s2));		// the side stream only: the small groups' kernel keeps running
+		memcpy(hc2, c->hScalar.p, 16);
+		const u32* lists2[3] = {c->dListSmall.p, c->dListDp.p, c->dListBig.p};
+		if (hc2[2] && sideStreams)
+		{
+			HIP_CHECK(hipEventRecord(c->evJoin3, s2));		// (used as a fork here: stream 3 starts behind the lists)
+			HIP_CHECK(hipStreamWaitEvent(s3, c->evJoin3, 0));
+		}
+#define FIN_ARGS2(cls) cp, lists2[cls], hc2[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, \
+		qLen, c->dGroupExt.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p, c->dTmp32.p, c->dCand.p, c->dPrimFlag.p
+#define DP_ARGS2(cls) cp, lists2[cls], hc2[cls], nGroups, nHits, c->dGroupStart.p, c->dGroupQuery.p, c->curQuery, c->dLen.p, qLen, \
+		c->dGroupExtSorted.p, c->dCur.p, c->dExt.p, c->dScore.p, c->dBack.p
+		for (int cls = 2; cls >= 1; --cls)
+		{
+			if (!hc2[cls]) continue;
+			hipStream_t on = cls == 2 ? s3 : s2;
+			{ ScopedK t(c->timer, "k_chain_dp", on);
+			  hipLaunchKernelGGL(k_chain_dp, (hc2[cls] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, on, DP_ARGS2(cls)); }
+			if (cls == 1 && smallCall2 && hugeMin2 <= (u32)FIN_CAP_M)
+			{
+				ScopedK t(c->timer, "k_chain_finish<lds1024>", on);
+				hipLaunchKernelGGL((k_chain_finish<FIN_CAP_M, 1>), hc2[cls], 64, FIN_CAP_M * 20, on, FIN_ARGS2(cls));
+			}
+			else
+			{
+				ScopedK t(c->timer, "k_chain_finish<global>", on);
+				hipLaunchKernelGGL((k_chain_finish<0, FIN_WAVES_G, FIN_BT_CAP>), (hc2[cls] + FIN_WAVES_G - 1) / FIN_WAVES_G, FIN_WAVES_G * 64, 0, on,
+								   FIN_ARGS2(cls));
+			}
+		}
+		if (hc2[0])		// groups above the fused kernel's cap that still fit the 256-hit LDS class (FG_FUSED_CAP < 256)
+		{
+			{ ScopedK t(c->timer, "k_chain_dp", s2);
+			  hipLaunchKernelGGL(k_chain_dp, (hc2[0] + DP_WAVES - 1) / DP_WAVES, DP_WAVES * 64, 0, s2, DP_ARGS2(0)); }
+			{ ScopedK t(c->timer, "k_chain_finish<lds256>", s2);
+			  hipLaunchKernelGGL((k_chain_finish<FIN_CAP_S, FIN_WAVES_S>), (hc2[0] + FIN_WAVES_S - 1) / FIN_WAVES_S, FIN_WAVES_S * 64,
+								 FIN_CAP_S * 20 * FIN_WAVES_S, s2, FIN_ARGS2(0)); }
+		}
+#undef DP_ARGS2
+#undef FIN_ARGS2
+		if (sideStreams)
+		{
+			HIP_CHECK(hipEventRecord(c->evJoin, s2));
+			HIP_CHECK(hipStreamWaitEvent(s, c->evJoin, 0));
+			if (hc2[2])
+			{
+				HIP_CHECK(hipEventRecord(c->evJoin3, s3));
+				HIP_CHECK(hipStreamWaitEvent(s, c->evJoin3, 0));
+			}
+		}
+		return;
+	}
 	// Both stages below run their big-group class on the side stream beside the small-group class on the main
 	// one: the classes are disjoint sets of groups, and the big-group kernels end with a handful of waves on an
 	// otherwise idle chip (long serial work per wave).  FG_CHAIN_STREAMS=1 puts everything on the main stream.
@@ -847,7 +1062,7 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	const bool smallCall = (nPrep[0] + nPrep[1]) < 65536u && !getenv("FG_CHAIN_NO_SMALL_CALL");
 	const u32 hugeMin = getenv("FG_CHAIN_HUGE_MIN") ? (u32)atoi(getenv("FG_CHAIN_HUGE_MIN")) : (smallCall ? (u32)FIN_CAP_M : 4096u);
 	{ ScopedK t(c->timer, "k_dp_list");
-	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, hugeMin, c->dListSmall.p, c->dListDp.p,
+	  hipLaunchKernelGGL(k_dp_list, gridG, WG, 0, s, nGroups, c->dDpSize.p, hugeMin, 0u, c->dListSmall.p, c->dListDp.p,
 						 c->dListBig.p, c->dListCnt.p); }
 	u32 hc[4];
 	HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 16, hipMemcpyDeviceToHost, s));

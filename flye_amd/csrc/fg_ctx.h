@@ -357,7 +357,7 @@ struct fg_ctx {
 	DevBuf<uint8_t> dGroupExtSorted;	// written by k_group_prep: the DP runs in extPos order (overlap.cpp:268-275)
 	DevBuf<u32> dTmp32;
 	DevBuf<u64> dCntA, dCntB, dGroupCnt, dGroupOff, dPrimCnt, dPrimOff, dDpGroups, dDpElems;
-	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListCnt;
+	DevBuf<u32> dPrimFlag, dDpSize, dListSmall, dListBig, dListDp, dListFused, dListCnt;
 	DevBuf<u32> dCur, dExt;		// (cur, ext) columns of the groups in DP order
 	DevBuf<char> dPrimOut;	// PrimRec array
 	// keep_alignment: per primary the chain's last hit (global hit index), its group's first
