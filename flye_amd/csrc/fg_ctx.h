@@ -367,6 +367,7 @@ struct fg_ctx {
 	PinnedBuf<u64> hMatches, hMatchOff;
 	PinnedBuf<u32> hMatchCnt;
 	DevBuf<char> dSortTasks, dSortBig;
+	DevBuf<u32> dSortCnt;		// task counts of the sort's level loop, a row per level (fg_overlap.hip)
 	DevBuf<int> dEditScratch;
 	DevBuf<u32> dEditList;		// pairs queued for the bit-vector kernel (two lists)
 	DevBuf<char> dEditCnt;

@@ -388,7 +388,8 @@ template <> struct ValPtr<PK> {
 // (<= SORT_CAP: k_sort_lds).  counts: [0] big, [1] small, [2] wide.
 __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTask* __restrict__ big,
 										   SortTask* __restrict__ wide, u32 wideMin,
-										   SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
+										   SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts /* [0] big, [2] wide */,
+										   u32* __restrict__ smallCnt)
 {
 	__shared__ u32 wcnt[3][WG / 64];
 	__shared__ u32 base[3];
@@ -403,7 +404,7 @@ __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTa
 	{
 		u32 tot = 0;
 		for (int i = 0; i < WG / 64; ++i) tot += wcnt[threadIdx.x][i];
-		base[threadIdx.x] = tot ? atomicAdd(&counts[threadIdx.x], tot) : 0u;
+		base[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 1 ? smallCnt : &counts[threadIdx.x], tot) : 0u;
 	}
 	__syncthreads();
 	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
@@ -419,9 +420,15 @@ __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, SortTa
 	__syncthreads();
 }
 
+// Task counts of the level loop live on the device, one row of four u32 per level: [0] one-wave tasks, [1] unused,
+// [2] workgroup (wide) tasks of that level; the number of small pieces queued for k_sort_lds (all levels together) sits
+// in its own word.  The kernels of level l read row l and route the children into row l + 1, looping over the tasks
+// with the grid they were given -- so the host can launch several levels in a row with grids sized by an upper bound
+// and read the real counts back only now and then (a round trip per level was 80 us of an otherwise idle chip for
+// each of the ~12 tail levels that hold a handful of pieces).
 __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __restrict__ big,
 							SortTask* __restrict__ wide, u32 wideMin,
-							SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
+							SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ levelCnt, u32* __restrict__ smallCnt)
 {
 	const u32 q = blockIdx.x * WG + threadIdx.x;
 	SortTask t{0, 0, 0};
@@ -430,7 +437,7 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 		const u64 n = hitOff[q + 1] - hitOff[q];
 		t.start = hitOff[q]; t.n = (u32)n; t.depth = n >= 2 ? 2 * fgsort::floor_log2_((int)n) : 0;
 	}
-	sort_route(t, q < nq, big, wide, wideMin, small, smallCap, counts);
+	sort_route(t, q < nq, big, wide, wideMin, small, smallCap, levelCnt, smallCnt);
 }
 
 // a workgroup of SORT_WIDE_WAVES waves per task: one partition of a huge piece
@@ -439,71 +446,81 @@ __global__ void k_sort_init(const u64* __restrict__ hitOff, u32 nq, SortTask* __
 #endif
 template <class KT>
 __global__ void __launch_bounds__(SORT_WIDE_WAVES * 64)
-k_sort_wide(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hitKey,
+k_sort_wide(const SortTask* __restrict__ tasks, const u32* __restrict__ levelCnt, KT* __restrict__ hitKey,
 			u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
-			SortTask* __restrict__ children)
+			SortTask* __restrict__ kids)
 {
 	__shared__ int shm[2 * SORT_WIDE_WAVES];
-	const u32 ti = blockIdx.x;
-	if (ti >= nTasks) return;
-	SortTask t = tasks[ti];
-	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
-	KT* K = hitKey + t.start;
-	typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
-	SortTask c0{0, 0, 0}, c1{0, 0, 0};
-	if (t.depth == 0)
+	const u32 nTasks = fg_uni(levelCnt[2]);
+	SortTask* children = kids + 2 * (size_t)fg_uni(levelCnt[0]);	// behind the one-wave tasks' children
+	for (u32 ti = blockIdx.x; ti < nTasks; ti += gridDim.x)
 	{
-		if (threadIdx.x == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		SortTask t = tasks[ti];
+		t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
+		KT* K = hitKey + t.start;
+		typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
+		SortTask c0{0, 0, 0}, c1{0, 0, 0};
+		if (t.depth == 0)
+		{
+			if (threadIdx.x == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		}
+		else
+		{
+			const int cut = wsort::partition_cf_block<KT, SORT_WIDE_WAVES>(K, V, (int)t.n, posScratch + t.start,
+																		   posScratch + nHits + t.start, shm);
+			c0 = SortTask{t.start, (u32)cut, t.depth - 1};
+			c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
+		}
+		if (threadIdx.x == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
+		__syncthreads();		// shm is reused by the block's next task
 	}
-	else
-	{
-		const int cut = wsort::partition_cf_block<KT, SORT_WIDE_WAVES>(K, V, (int)t.n, posScratch + t.start,
-																	   posScratch + nHits + t.start, shm);
-		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
-		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
-	}
-	if (threadIdx.x == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
 }
 
 // one wave per task: one partition (or the depth-limit heapsort); children to slots 2i, 2i+1
 template <class KT>
-__global__ void k_sort_level(const SortTask* __restrict__ tasks, u32 nTasks, KT* __restrict__ hitKey,
+__global__ void k_sort_level(const SortTask* __restrict__ tasks, const u32* __restrict__ levelCnt, KT* __restrict__ hitKey,
 							 u32* __restrict__ hitVal, u32* __restrict__ posScratch, u64 nHits,
 							 SortTask* __restrict__ children, u32 streamMax)
 {
 	const int lane = threadIdx.x & 63;
-	const u32 ti = blockIdx.x * SORT_LEVEL_WAVES + (threadIdx.x >> 6);
-	if (ti >= nTasks) return;
-	SortTask t = tasks[ti];
-	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
-	KT* K = hitKey + t.start;
-	typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
-	SortTask c0{0, 0, 0}, c1{0, 0, 0};
-	if (t.depth == 0)
+	const u32 nTasks = fg_uni(levelCnt[0]);
+	for (u32 ti = blockIdx.x * SORT_LEVEL_WAVES + (threadIdx.x >> 6); ti < nTasks; ti += gridDim.x * SORT_LEVEL_WAVES)
 	{
-		if (lane == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		SortTask t = tasks[ti];
+		t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
+		KT* K = hitKey + t.start;
+		typename ValPtr<KT>::type V = ValPtr<KT>::at(hitVal, t.start);
+		SortTask c0{0, 0, 0}, c1{0, 0, 0};
+		if (t.depth == 0)
+		{
+			if (lane == 0) { wsort::PtrAcc<KT, typename ValPtr<KT>::type> acc{K, V}; fgsort::heap_sort_(acc, 0, (int)t.n); }
+		}
+		else
+		{
+			// many medium pieces in flight: the streamed form moves fewer bytes; few huge pieces:
+			// the closed form has no serial chain
+			const int cut = t.n <= streamMax
+				? wsort::partition_stream(K, V, 0, (int)t.n)
+				: wsort::partition_cf(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
+			c0 = SortTask{t.start, (u32)cut, t.depth - 1};
+			c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
+		}
+		if (lane == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
 	}
-	else
-	{
-		// many medium pieces in flight: the streamed form moves fewer bytes; few huge pieces:
-		// the closed form has no serial chain
-		const int cut = t.n <= streamMax
-			? wsort::partition_stream(K, V, 0, (int)t.n)
-			: wsort::partition_cf(K, V, 0, (int)t.n, posScratch + t.start, posScratch + nHits + t.start);
-		c0 = SortTask{t.start, (u32)cut, t.depth - 1};
-		c1 = SortTask{t.start + (u64)cut, t.n - (u32)cut, t.depth - 1};
-	}
-	if (lane == 0) { children[2 * (u64)ti] = c0; children[2 * (u64)ti + 1] = c1; }
 }
 
-__global__ void k_sort_route(const SortTask* __restrict__ children, u32 nChildren, SortTask* __restrict__ big,
+__global__ void k_sort_route(const SortTask* __restrict__ children, const u32* __restrict__ levelCnt, SortTask* __restrict__ big,
 							 SortTask* __restrict__ wide, u32 wideMin,
-							 SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ counts)
+							 SortTask* __restrict__ small, u32 smallCap, u32* __restrict__ nextCnt, u32* __restrict__ smallCnt)
 {
-	const u32 i = blockIdx.x * WG + threadIdx.x;
-	SortTask t{0, 0, 0};
-	if (i < nChildren) t = children[i];
-	sort_route(t, i < nChildren, big, wide, wideMin, small, smallCap, counts);
+	const u32 nChildren = 2 * (levelCnt[0] + levelCnt[2]);
+	for (u32 base = blockIdx.x * WG; base < nChildren; base += gridDim.x * WG)		// uniform per block: sort_route has barriers
+	{
+		const u32 i = base + threadIdx.x;
+		SortTask t{0, 0, 0};
+		if (i < nChildren) t = children[i];
+		sort_route(t, i < nChildren, big, wide, wideMin, small, smallCap, nextCnt, smallCnt);
+	}
 }
 
 template <class KT>
@@ -833,6 +850,7 @@ T fetchScalar(fg_ctx* c, const T* dptr)
 } // namespace
 
 // std::sort order of each segment [segOff[i], segOff[i+1]) of device arrays K, V
+#define SORT_MAX_LEVELS 128		// rows of level counts (the depth budget of 2 log2 n bounds the levels: n < 2^31)
 template <class KT>
 static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* dV, u64 nHits, int curBits = 0)
 {
@@ -844,28 +862,34 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	c->dSortTasks.reserve((size_t)smallCap * sizeof(SortTask));
 	c->dSortBig.reserve((size_t)(6 * bigCap) * sizeof(SortTask));
 	c->dListCnt.reserve(4);
+	c->dSortCnt.reserve(4 * (SORT_MAX_LEVELS + 2) + 4);
 	SortTask* smallT = (SortTask*)c->dSortTasks.p;
 	SortTask* bigA = (SortTask*)c->dSortBig.p;
 	SortTask* bigB = bigA + bigCap;
 	SortTask* kids = bigB + bigCap;	// 2 * bigCap
 	SortTask* wideA = kids + 2 * bigCap;
 	SortTask* wideB = wideA + bigCap;
+	u32* levelCnt = c->dSortCnt.p;							// row l at levelCnt + 4 l
+	u32* smallCnt = c->dSortCnt.p + 4 * (SORT_MAX_LEVELS + 2);
 	const u32 streamMax = getenv("FG_SORT_STREAM_MAX") ? (u32)atoi(getenv("FG_SORT_STREAM_MAX")) : 8192u;
 	const u32 wideMin = getenv("FG_SORT_WIDE_MIN") ? (u32)atoi(getenv("FG_SORT_WIDE_MIN")) : 16384u;
-	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 12, s));
+	HIP_CHECK(hipMemsetAsync(c->dSortCnt.p, 0, c->dSortCnt.bytes(), s));
 	{ ScopedK t(c->timer, "k_sort_level");
 	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, bigA, wideA, wideMin, smallT, smallCap,
-						 c->dListCnt.p); }
-	u32 cnt[3];
-	auto fetchCounts = [&]()
+						 levelCnt, smallCnt); }
+	// counts of level `lvl` (and the small pieces queued so far) to the host
+	u32 cnt[3] = {0, 0, 0};		// big, small (total), wide
+	auto fetchCounts = [&](int lvl)
 	{
 		c->hScalar.reserve(8);
-		HIP_CHECK(hipMemcpyAsync(c->hScalar.p, c->dListCnt.p, 12, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync(c->hScalar.p, levelCnt + 4 * lvl, 16, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync((char*)c->hScalar.p + 16, smallCnt, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		memcpy(cnt, c->hScalar.p, 12);
+		u32 row[5];
+		memcpy(row, c->hScalar.p, 20);
+		cnt[0] = row[0]; cnt[2] = row[2]; cnt[1] = row[4];
 	};
-	fetchCounts();
-	u32 nBig = cnt[0], nWide = cnt[2];
+	fetchCounts(0);
 	static const bool trace = getenv("FG_SORT_TRACE") != nullptr;
 	static const char* levelNames[32] = {
 		"k_sort_level#00", "k_sort_level#01", "k_sort_level#02", "k_sort_level#03", "k_sort_level#04", "k_sort_level#05",
@@ -874,57 +898,46 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 		"k_sort_level#18", "k_sort_level#19", "k_sort_level#20", "k_sort_level#21", "k_sort_level#22", "k_sort_level#23",
 		"k_sort_level#24", "k_sort_level#25", "k_sort_level#26", "k_sort_level#27", "k_sort_level#28", "k_sort_level#29",
 		"k_sort_level#30", "k_sort_level#31+"};
-	// FG_SORT_STREAMS=2 (experiment, off): pieces that have become small leave for the LDS kernel at once, on the
-	// side stream beside the next partition level.  Measured at the bench workload: the levels stretch from 12.1 to
-	// 18.8 ms and the pass gets 1 ms LONGER -- small pieces only appear in numbers when the levels are nearly
-	// done, and the two kernels then compete for the same CUs.  Default: one launch at the end.
-	const bool twoStreams = getenv("FG_SORT_STREAMS") && atoi(getenv("FG_SORT_STREAMS")) == 2;
 	const u64 narrowMax = getenv("FG_NARROW_MAX") ? strtoull(getenv("FG_NARROW_MAX"), nullptr, 10) : 0xFFFFFFFFULL;
-	u32 smallDone = 0;
-	bool forked = false;
-	auto launchSmall = [&](u32 upTo, hipStream_t on)
-	{
-		if (upTo > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
-		if (upTo <= smallDone) return;
-		const u32 cntNew = upTo - smallDone;
-		ScopedK t(c->timer, "k_sort_lds", on);
-		hipLaunchKernelGGL(k_sort_lds<KT>, (cntNew + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, on,
-						   smallT + smallDone, cntNew, dK, dV, curBits, narrowMax, c->dTmp32.p, nHits);
-		smallDone = upTo;
-	};
+	// levels between two read-backs of the counts: grids are sized by an upper bound (a level has at most twice the
+	// tasks of the one before) and the kernels loop over what is really there.  FG_SORT_LEVEL_BATCH=1: a read-back per
+	// level, as until round 3 (also what the per-level trace uses).
+	const int levelBatch = trace ? 1 : (getenv("FG_SORT_LEVEL_BATCH") ? std::max(1, atoi(getenv("FG_SORT_LEVEL_BATCH"))) : 4);
 	int level = 0;
-	while (nBig || nWide)
+	while (cnt[0] || cnt[2])
 	{
-		if (twoStreams && cnt[1] - smallDone >= 4096)
+		u64 ubBig = cnt[0], ubWide = cnt[2];
+		for (int b = 0; b < levelBatch && level < SORT_MAX_LEVELS; ++b)
 		{
-			// everything queued so far was written by launches the host has synchronised with
-			if (!forked) { HIP_CHECK(hipEventRecord(c->evFork, s)); HIP_CHECK(hipStreamWaitEvent(c->stream2, c->evFork, 0)); forked = true; }
-			launchSmall(cnt[1], c->stream2);
+			if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks, %u small pieces so far\n", level, cnt[0], cnt[2], cnt[1]);
+			ScopedK t(c->timer, trace ? levelNames[level < 31 ? level : 31] : "k_sort_level");
+			const u32* rowL = levelCnt + 4 * level;
+			u32* rowN = levelCnt + 4 * (level + 1);
+			if (ubWide)	// the long poles first
+				hipLaunchKernelGGL(k_sort_wide<KT>, (unsigned)std::min<u64>(ubWide, 2048), SORT_WIDE_WAVES * 64, 0, s, wideA, rowL, dK, dV,
+								   c->dTmp32.p, nHits, kids);
+			if (ubBig)
+				hipLaunchKernelGGL(k_sort_level<KT>, (unsigned)std::min<u64>((ubBig + SORT_LEVEL_WAVES - 1) / SORT_LEVEL_WAVES, 1u << 20),
+								   SORT_LEVEL_WAVES * 64, 0, s, bigA, rowL, dK, dV, c->dTmp32.p, nHits, kids, streamMax);
+			const u64 ubKids = 2 * (ubBig + ubWide);
+			hipLaunchKernelGGL(k_sort_route, (unsigned)std::min<u64>((ubKids + WG - 1) / WG, 4096), WG, 0, s, kids, rowL, bigB, wideB, wideMin,
+							   smallT, smallCap, rowN, smallCnt);
+			++level;
+			std::swap(bigA, bigB);
+			std::swap(wideA, wideB);
+			// what the next level can hold at most
+			const u64 nb = std::min<u64>(ubKids, bigCap), nw = std::min<u64>(ubKids, nHits / wideMin + 1);
+			ubBig = nb; ubWide = nw;
 		}
-		HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 4, s));
-		HIP_CHECK(hipMemsetAsync(c->dListCnt.p + 2, 0, 4, s));
-		if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks, %u small pieces so far\n", level, nBig, nWide, cnt[1]);
-		ScopedK t(c->timer, trace ? levelNames[level < 31 ? level : 31] : "k_sort_level");
-		++level;
-		if (nWide)	// the long poles first
-			hipLaunchKernelGGL(k_sort_wide<KT>, nWide, SORT_WIDE_WAVES * 64, 0, s, wideA, nWide, dK, dV, c->dTmp32.p, nHits,
-							   kids + 2 * (size_t)nBig);
-		if (nBig)
-			hipLaunchKernelGGL(k_sort_level<KT>, (nBig + SORT_LEVEL_WAVES - 1) / SORT_LEVEL_WAVES, SORT_LEVEL_WAVES * 64, 0, s, bigA, nBig, dK, dV, c->dTmp32.p, nHits,
-							   kids, streamMax);
-		const u32 nKids = 2 * (nBig + nWide);
-		hipLaunchKernelGGL(k_sort_route, (nKids + WG - 1) / WG, WG, 0, s, kids, nKids, bigB, wideB, wideMin, smallT, smallCap,
-						   c->dListCnt.p);
-		fetchCounts();
-		nBig = cnt[0]; nWide = cnt[2];
-		std::swap(bigA, bigB);
-		std::swap(wideA, wideB);
+		if (level >= SORT_MAX_LEVELS) throw FgError{FG_ERR_HIP, "internal: sort level budget exceeded"};
+		fetchCounts(level);
 	}
-	launchSmall(cnt[1], s);
-	if (forked)
+	if (cnt[1] > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
+	if (cnt[1])
 	{
-		HIP_CHECK(hipEventRecord(c->evJoin, c->stream2));
-		HIP_CHECK(hipStreamWaitEvent(s, c->evJoin, 0));
+		ScopedK t(c->timer, "k_sort_lds");
+		hipLaunchKernelGGL(k_sort_lds<KT>, (cnt[1] + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
+						   smallT, cnt[1], dK, dV, curBits, narrowMax, c->dTmp32.p, nHits);
 	}
 }
 
