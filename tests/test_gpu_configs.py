@@ -106,26 +106,18 @@ def test_config4_synthetic_10gb_rank0_of_8(built):
           f"{n} sampled records identical to the oracle")
 
 
-def test_config5_hifi_proxy_rank0_of_8_bounded_memory(built):
-    """configs[4] "Human CHM13 HiFi 30x, 8 x MI355X" on the survey's proxy (SURVEY.md §8d: 310 Mb genome, 30x,
-    9.3 Gbp of HiFi reads, asm_hifi.cfg: minimizer index w = 10, base-level divergence on homopolymer-compressed
-    sequence).  The gate: the synthetic reads carry 0.3 % error EACH, so true overlaps diverge by ~0.6 %; the
-    --hifi-error 0.003 gate of the real data set would reject them all, the test's gate is 0.01.
+def config5_rank0_of_8(genome_len: int, n_sample: int = 120):
+    """What test_config5_hifi_proxy_rank0_of_8_bounded_memory does, at any genome size (tools/config5_scale.py runs it
+    at 1 Gb = a third of CHM13)."""
 
-    What one rank of eight does, on one GPU: the batched selection over all reads, ITS key range sorted and
-    run-length encoded, finish with the sums over all ranks -> its piece; the gather of the eight pieces straight
-    into the context's own arrays; then its share of the queries (i % 8 == 0) against the full index.
-    Checked: (1) the device memory the library holds never exceeds a stated bound during the rank's build;
-    (2) the piece equals the same key range of the index built the one-GPU way; (3) the gathered index equals
-    that index; (4) >= 100 sampled query reads against the CPU oracle, record for record."""
     import torch
     from flye_amd import config, dist, gpu, workloads
     W = 8
     t0 = time.time()
-    rs, min_ovlp, preset = workloads.hifi30(genome_len=310_000_000)
+    rs, min_ovlp, preset = workloads.hifi30(genome_len=genome_len)
     cfg = config.preset(preset)
     k = int(cfg["kmer_size"])
-    assert rs.total_bases > 9e9
+    assert rs.total_bases > 25 * genome_len
     t_gen = time.time() - t0
 
     # ---- the index the one-GPU way (in 8 key-range steps), kept on the host as the yardstick
@@ -142,7 +134,7 @@ def test_config5_hifi_proxy_rank0_of_8_bounded_memory(built):
     ctx.close()
     del vi, ctx
     t_full = time.time() - t0 - t_gen
-    assert st_full["index_entries"] > 1.4e9
+    assert st_full["index_entries"] > 4 * genome_len
     key_lo = [np.uint64(lo) << np.uint64(2 * k - 12) for lo, hi in ranges]
     cut = np.searchsorted(full.keys, np.array(key_lo, np.uint64)).tolist() + [len(full.keys)]
     rcut = np.searchsorted(full.repetitive, np.array(key_lo, np.uint64)).tolist() + [len(full.repetitive)]
@@ -212,12 +204,27 @@ def test_config5_hifi_proxy_rank0_of_8_bounded_memory(built):
     assert np.all(res.recs["seq_divergence"] < 0.01) and np.all(res.recs["edit_distance"] >= 0)
     bp = int(rs.length[(q // 2).astype(np.int64)].sum())
     rng = np.random.default_rng(6)
-    sample = np.sort(rng.choice(len(q), size=120, replace=False))
+    sample = np.sort(rng.choice(len(q), size=n_sample, replace=False))
     n = _sampled_oracle_check(rs, cfg, vi, det, res, q, sample, k, ex=full)
     _, peak_all = gpu.memory_stats()
     ctx.close()
-    print(f"hifi proxy 310 Mb, rank 0/8: {rs.n} reads {rs.total_bases / 1e9:.2f} Gbp (gen {t_gen:.0f} s), one-GPU build + export "
+    print(f"hifi proxy {genome_len / 1e6:.0f} Mb, rank 0/8: {rs.n} reads {rs.total_bases / 1e9:.2f} Gbp (gen {t_gen:.0f} s), one-GPU build + export "
           f"{t_full:.0f} s, rank build + gather {t_rank:.0f} s; reads {reads_bytes / 1e9:.2f} GB, rank-0 entries {e0 / 1e6:.0f} M of "
           f"{E / 1e6:.0f} M, build peak {peak / 1e9:.2f} GB (bound {bound / 1e9:.2f}), reads + full index {index_bytes / 1e9:.2f} GB, "
           f"peak incl. overlap scratch {peak_all / 1e9:.2f} GB; {len(q)} queries {bp / 1e9:.2f} Gbp in {t2 - t1:.1f} s "
           f"({bp / (t2 - t1) / 1e9:.2f} Gbp/s), {len(res.recs)} overlaps, {n} sampled records identical to the oracle")
+
+
+def test_config5_hifi_proxy_rank0_of_8_bounded_memory(built):
+    """configs[4] "Human CHM13 HiFi 30x, 8 x MI355X" on the survey's proxy (SURVEY.md §8d: 310 Mb genome, 30x,
+    9.3 Gbp of HiFi reads, asm_hifi.cfg: minimizer index w = 10, base-level divergence on homopolymer-compressed
+    sequence).  The gate: the synthetic reads carry 0.3 % error EACH, so true overlaps diverge by ~0.6 %; the
+    --hifi-error 0.003 gate of the real data set would reject them all, the test's gate is 0.01.
+
+    What one rank of eight does, on one GPU: the batched selection over all reads, ITS key range sorted and
+    run-length encoded, finish with the sums over all ranks -> its piece; the gather of the eight pieces straight
+    into the context's own arrays; then its share of the queries (i % 8 == 0) against the full index.
+    Checked: (1) the device memory the library holds never exceeds a stated bound during the rank's build;
+    (2) the piece equals the same key range of the index built the one-GPU way; (3) the gathered index equals
+    that index; (4) >= 100 sampled query reads against the CPU oracle, record for record."""
+    config5_rank0_of_8(310_000_000)
