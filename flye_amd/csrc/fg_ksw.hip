@@ -440,6 +440,250 @@ k_ksw_extz2_lds(const KswJob* __restrict__ jobs, const u32* __restrict__ order, 
 	}
 }
 
+// ---- the same recurrences with the state in REGISTERS --------------------------------------------------------------
+// The LDS form above pays two LDS round trips per anti-diagonal (read what the cells need, write what they produce), and
+// a diagonal depends on the one before: ~1.2 us per diagonal at band 64 however empty the chip is -- a 10 kb pair takes
+// ~20 ms, and a batch of a few hundred pairs (the consensus of one genome's disjointigs) is bound by that latency.
+// Here u, v, x, y, s of the cells a diagonal can touch live in registers, as a WINDOW relative to the diagonal's first
+// cell: cell 64 c + lane of the window = target position st + 64 c + lane (c < NCH; 64 NCH > band + 30).  The left
+// neighbour's old x, v come by one DPP lane shift (lane 0 of a chunk from lane 63 of the chunk below); st only ever grows,
+// by 16 at a time (it is rounded down to the vector width), and then the window slides down 16 lanes through the LDS
+// crossbar (ds_bpermute: no memory access) -- positions that slide in from above were never touched and hold the zeros of
+// the reference's calloc'ed arrays, positions that slide out below are never read again except st - 1, which is taken
+// before the slide.  Target and query bytes still come from LDS rings (they do not depend on the recurrence).
+// Same bytes as the two kernels above for every cell it computes, same direction matrix, same backtrack.
+__device__ __forceinline__ u32 ksw_shr1(u32 v, u32 fill)
+{
+	return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);	// lane L <- lane L - 1, lane 0 <- fill
+}
+
+template <int RING, int NCH, int G, int ROWMAX>
+__global__ void __launch_bounds__(64)
+k_ksw_extz2_reg(const KswJob* __restrict__ jobs, const u32* __restrict__ order, u32 nJobs, const uint8_t* __restrict__ trgAll,
+				const uint8_t* __restrict__ qryAll, uint8_t* __restrict__ scratch, u32* __restrict__ cigars, u32* __restrict__ nCigar,
+				u32* __restrict__ dense, u32* __restrict__ total, u32* __restrict__ runBase, u32 dbg)
+{
+	constexpr int SMEM = 2 * RING + G * ROWMAX > KSW_TILE_BYTES ? 2 * RING + G * ROWMAX : KSW_TILE_BYTES;
+	__shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+	uint8_t* const sT = smem; uint8_t* const sQ = smem + RING;
+	uint8_t* const sStage = smem + 2 * RING;
+	uint8_t* const sTile = smem;
+	const int lane = threadIdx.x;
+	constexpr int M = RING - 1;
+	const int slideAddr = ((lane + 16) & 63) << 2;
+	for (u32 jo = blockIdx.x; jo < nJobs; jo += gridDim.x)
+	{
+		const u32 jb = order[jo];
+		const KswJob J = jobs[jb];
+		const int tlen = J.tlen, qlen = J.qlen, w = J.w;
+		const uint8_t* target = trgAll + J.trgOff;
+		const uint8_t* query = qryAll + J.qryOff;
+		const int T16 = (tlen + 15) / 16 * 16;
+		const int q = 4, e = 2, qe = q + e, m = 5;
+		const int scMch = 2, scMis = -4, scN = -e;
+		const uint8_t qe2 = (uint8_t)(qe * 2), maxSc = (uint8_t)(scMch + qe * 2);
+		int nCol = min(qlen, tlen);
+		nCol = ((nCol < w + 1 ? nCol : w + 1) + 15) / 16 + 1;
+		const int rowBytes = nCol * 16;
+		uint8_t* P = scratch + J.pOff;
+		lds_fence();		// the previous job's walk is done with the tile
+		for (int i = lane; i < RING; i += 64)
+		{
+			sT[i] = i < tlen ? target[i] : 0;
+			sQ[i] = i < qlen ? query[i] : 0;
+		}
+		int tLoaded = RING;		// target ring holds positions [tLoaded - RING, tLoaded)
+		int qLoaded = RING;		// query ring holds positions [qLoaded - RING, qLoaded)
+		lds_fence();
+		// the window: all zeros (calloc), first cell at position 0
+		u32 U[NCH], V[NCH], X[NCH], Y[NCH], S[NCH];
+#pragma unroll
+		for (int c = 0; c < NCH; ++c) { U[c] = 0; V[c] = 0; X[c] = 0; Y[c] = 0; S[c] = 0; }
+		int wst = 0;
+		int lastSt = -1, lastEn = -1;
+		const int R = (dbg & 1) ? 0 : qlen + tlen - 1;		// dbg: timing experiments (FG_KSW_DEBUG), results are then wrong
+		for (int r = 0; r < R; ++r)
+		{
+			int st, en;
+			ksw_bounds(r, qlen, tlen, w, st, en);
+			const int st0 = st, en0 = en;
+			st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+			const int pieceEnd = min(T16 - 1, st0 + (en0 - st0) / 16 * 16 + 15);
+			if (tLoaded <= pieceEnd || qLoaded <= r - st0)
+			{
+				while (tLoaded <= pieceEnd)
+				{
+					const int t = tLoaded + lane;
+					sT[t & M] = t < tlen ? target[t] : 0;
+					tLoaded += 64;
+				}
+				while (qLoaded <= r - st0)
+				{
+					const int jq = qLoaded + lane;
+					sQ[jq & M] = jq < qlen ? query[jq] : 0;
+					qLoaded += 64;
+				}
+				lds_fence();
+			}
+			const bool prevHas = st - 1 >= lastSt && st - 1 <= lastEn;
+			// the target / query bytes of this diagonal's cells: issued first, waited for behind the register work below
+			uint8_t tq[NCH], tb[NCH];
+#pragma unroll
+			for (int c = 0; c < NCH; ++c)
+			{
+				const int t = st + 64 * c + lane;
+				tq[c] = sT[t & M]; tb[c] = sQ[(r - t) & M];
+			}
+			// the window follows st: 16 lanes down (st - 1 = cell 15 of the old window is kept for the first cell)
+			u32 xEdge = 0, vEdge = 0;
+			if (st != wst)
+			{
+				xEdge = (u32)__builtin_amdgcn_readlane((int)X[0], 15);
+				vEdge = (u32)__builtin_amdgcn_readlane((int)V[0], 15);
+				u32 nU[NCH], nV[NCH], nX[NCH], nY[NCH], nS[NCH];
+#pragma unroll
+				for (int c = 0; c < NCH; ++c)
+				{
+					const bool low = lane < 48;
+					const u32 aU = (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)U[c]), bU = c + 1 < NCH ? (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)U[c + 1 < NCH ? c + 1 : c]) : 0u;
+					const u32 aV = (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)V[c]), bV = c + 1 < NCH ? (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)V[c + 1 < NCH ? c + 1 : c]) : 0u;
+					const u32 aX = (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)X[c]), bX = c + 1 < NCH ? (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)X[c + 1 < NCH ? c + 1 : c]) : 0u;
+					const u32 aY = (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)Y[c]), bY = c + 1 < NCH ? (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)Y[c + 1 < NCH ? c + 1 : c]) : 0u;
+					const u32 aS = (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)S[c]), bS = c + 1 < NCH ? (u32)__builtin_amdgcn_ds_bpermute(slideAddr, (int)S[c + 1 < NCH ? c + 1 : c]) : 0u;
+					nU[c] = low ? aU : bU; nV[c] = low ? aV : bV; nX[c] = low ? aX : bX; nY[c] = low ? aY : bY; nS[c] = low ? aS : bS;
+				}
+#pragma unroll
+				for (int c = 0; c < NCH; ++c) { U[c] = nU[c]; V[c] = nV[c]; X[c] = nX[c]; Y[c] = nY[c]; S[c] = nS[c]; }
+				wst = st;
+			}
+			// the left neighbours' old x, v, before any cell of this diagonal is written
+			u32 x1r[NCH], v1r[NCH];
+#pragma unroll
+			for (int c = 0; c < NCH; ++c)
+			{
+				const u32 fx = c ? (u32)__builtin_amdgcn_readlane((int)X[c ? c - 1 : 0], 63) : 0u;
+				const u32 fv = c ? (u32)__builtin_amdgcn_readlane((int)V[c ? c - 1 : 0], 63) : 0u;
+				x1r[c] = ksw_shr1(X[c], fx); v1r[c] = ksw_shr1(V[c], fv);
+			}
+			lds_fence();		// tq, tb
+			uint8_t* Prow = sStage + (r & (G - 1)) * rowBytes;
+#pragma unroll
+			for (int c = 0; c < NCH; ++c)
+			{
+				const int t = st + 64 * c + lane;
+				// the score pieces cover st0 .. pieceEnd (query position r - t, zeros behind its start); outside
+				// them s keeps what an earlier diagonal left
+				const bool piece = t >= st0 && t <= pieceEnd;
+				const uint8_t sb = r - t >= 0 ? tb[c] : (uint8_t)0;
+				const bool wild = tq[c] == (uint8_t)(m - 1) || sb == (uint8_t)(m - 1);
+				const uint8_t sc = piece ? (uint8_t)(wild ? scN : (tq[c] == sb ? scMch : scMis)) : (uint8_t)S[c];
+				S[c] = sc;
+				if (t <= en)
+				{
+					uint8_t x1 = (uint8_t)x1r[c], v1 = (uint8_t)v1r[c], u = (uint8_t)U[c], y = (uint8_t)Y[c];
+					if (t == st)
+					{
+						// left of the first cell: the previous diagonal's cell if it had one there
+						if (st > 0) { if (prevHas) { x1 = (uint8_t)xEdge; v1 = (uint8_t)vEdge; } else x1 = v1 = 0; }
+						else { x1 = 0; v1 = r ? (uint8_t)q : 0; }
+					}
+					if (t == r) { y = 0; u = r ? (uint8_t)q : 0; }		// the first row's boundary (en >= r here)
+					uint8_t z = (uint8_t)(sc + qe2);
+					const uint8_t a = (uint8_t)(x1 + v1), b = (uint8_t)(y + u);
+					uint8_t d = (int8_t)a > (int8_t)z ? 1 : 0;
+					z = (int8_t)z > 0 ? z : 0;
+					z = max(z, a);
+					if ((int8_t)b > (int8_t)z) d = 2;
+					z = max(z, b);
+					z = min(z, maxSc);
+					const uint8_t nu = (uint8_t)(z - v1), nv = (uint8_t)(z - u);
+					const uint8_t zq = (uint8_t)(z - q);
+					const uint8_t a2 = (uint8_t)(a - zq), b2 = (uint8_t)(b - zq);
+					uint8_t nx = 0, ny = 0;
+					if ((int8_t)a2 > 0) { nx = a2; d |= 0x08; }
+					if ((int8_t)b2 > 0) { ny = b2; d |= 0x10; }
+					U[c] = nu; V[c] = nv; X[c] = nx; Y[c] = ny;
+					if (t - st < rowBytes) Prow[t - st] = d;
+				}
+			}
+			lds_fence();
+			lastSt = st; lastEn = en;
+			if ((r & (G - 1)) == G - 1 || r == R - 1)
+			{
+				const int r0 = r & ~(G - 1);
+				uint4* dst = (uint4*)(P + (size_t)r0 * rowBytes);		// rows are 16-byte multiples, P is 16-byte aligned
+				for (int k = lane; k < (r - r0 + 1) * (rowBytes / 16); k += 64) dst[k] = ((const uint4*)sStage)[k];
+			}
+		}
+		ksw_fence();		// the direction bytes are in memory
+		// backtrack on tiles of the direction matrix staged in LDS; every lane follows the same walk (broadcast
+		// reads), lane 0 records the runs.  While the walk is in the match state, the lanes look at the next 64
+		// cells down the diagonal at once and take the whole stretch that stays in that state as one run.
+		u32* cig = cigars + J.cigOff;
+		int n = 0;
+		{
+			const int tileRows = max(1, min(128, KSW_TILE_BYTES / rowBytes));
+			int tileLo = 0x7fffffff, tileHi = -1;	// rows [tileLo, tileHi] are staged
+			int i = (dbg & 2) ? -1 : tlen - 1, j = qlen - 1, state = 0;
+			u32 curOp = 0xFFFFFFFFu, curLen = 0;
+			bool lookAhead = !(dbg & 4);
+			auto push = [&](u32 op, u32 len)
+			{
+				if (op == curOp) curLen += len;
+				else { if (curOp != 0xFFFFFFFFu) { if (lane == 0) cig[n] = curLen << 4 | curOp; ++n; } curOp = op; curLen = len; }
+			};
+			while (i >= 0 && j >= 0)
+			{
+				const int r = i + j;
+				if (r < tileLo || r > tileHi)
+				{
+					lds_fence();
+					tileHi = r; tileLo = max(0, r - tileRows + 1);
+					const int bytes = (tileHi - tileLo + 1) * rowBytes;
+					const uint4* src = (const uint4*)(P + (size_t)tileLo * rowBytes);	// rows are 16-byte multiples
+					for (int k = lane; k < bytes / 16; k += 64) ((uint4*)sTile)[k] = src[k];
+					lds_fence();
+				}
+				if (state == 0 && lookAhead)
+				{
+					const int ik = i - lane, jk = j - lane, rk = r - 2 * lane;
+					bool isM = false;
+					if (ik >= 0 && jk >= 0 && rk >= tileLo)
+					{
+						int stk, enk;
+						ksw_bounds(rk, qlen, tlen, w, stk, enk);
+						stk = stk / 16 * 16; enk = (enk + 16) / 16 * 16 - 1;
+						if (ik >= stk && ik <= enk) isM = (sTile[(rk - tileLo) * rowBytes + ik - stk] & 7) == 0;
+					}
+					const u64 notM = ~__ballot(isM);
+					const int L = notM ? __builtin_ctzll(notM) : 64;
+					lookAhead = false;		// the cell behind the stretch takes the step below
+					if (L > 0) { push(0, (u32)L); i -= L; j -= L; continue; }
+				}
+				lookAhead = !(dbg & 4);
+				int st, en;
+				ksw_bounds(r, qlen, tlen, w, st, en);
+				st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+				int force = -1;
+				if (i < st) force = 2;
+				if (i > en) force = 1;
+				const u32 tmp = force < 0 ? (u32)sTile[(r - tileLo) * rowBytes + i - st] : 0u;
+				if (state == 0) state = tmp & 7;
+				else if (!((tmp >> (state + 2)) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (force >= 0) state = force;
+				if (state == 0) { push(0, 1); --i; --j; }
+				else if (state == 1 || state == 3) { push(2, 1); --i; }
+				else { push(1, 1); --j; }
+			}
+			if (i >= 0) push(2, (u32)i + 1);
+			if (j >= 0) push(1, (u32)j + 1);
+			if (curOp != 0xFFFFFFFFu) { if (lane == 0) cig[n] = curLen << 4 | curOp; ++n; }
+		}
+		ksw_emit_runs(cig, n, jb, dense, total, runBase, nCigar, lane);
+	}
+}
+
 // does the band w connect (0, 0) with (tlen-1, qlen-1)?  ksw_extz2 gives up ("band too narrow", st > en on some
 // diagonal r) otherwise.  st = max(0, r-qlen+1, (r-w+1)>>1), en = min(tlen-1, r, (r+w)>>1): of the nine
 // (lower, upper) pairs only r-qlen+1 > (r+w)>>1 and (r-w+1)>>1 > tlen-1 can happen, and both differences never
@@ -567,7 +811,13 @@ void fgKswAlign(fg_ctx* c, u32 nPairs, const uint8_t* trg, const u64* trgOff, co
 				const u32* ord = dOrder.p + at;
 #define KSW_ARGS dJobs.p, ord, cnt, dTrg.p, dQry.p, dScratch.p, dCig.p, dN.p, dDense.p, dTotal.p, dBase.p
 				const u32 dbg = getenv("FG_KSW_DEBUG") ? (u32)atoi(getenv("FG_KSW_DEBUG")) : 0u;
+				// state in registers (FG_KSW_REG=0: in LDS rings, the round-2 form)
+				const bool regForm = !(getenv("FG_KSW_REG") && atoi(getenv("FG_KSW_REG")) == 0);
 				if (cls == 0) hipLaunchKernelGGL(k_ksw_extz2, g, 64, 0, s, KSW_ARGS);
+				else if (regForm && cls == 1) hipLaunchKernelGGL((k_ksw_extz2_reg<256, 2, 8, 96>), g, 64, 0, s, KSW_ARGS, dbg);
+				else if (regForm && cls == 2) hipLaunchKernelGGL((k_ksw_extz2_reg<256, 3, 8, 160>), g, 64, 0, s, KSW_ARGS, dbg);
+				else if (regForm && cls == 3) hipLaunchKernelGGL((k_ksw_extz2_reg<512, 5, 4, 288>), g, 64, 0, s, KSW_ARGS, dbg);
+				else if (regForm) hipLaunchKernelGGL((k_ksw_extz2_reg<1024, 9, 2, 544>), g, 64, 0, s, KSW_ARGS, dbg);
 				else if (cls == 1) hipLaunchKernelGGL((k_ksw_extz2_lds<256, 2, 8, 96>), g, 64, 0, s, KSW_ARGS, dbg);
 				else if (cls == 2) hipLaunchKernelGGL((k_ksw_extz2_lds<256, 3, 8, 160>), g, 64, 0, s, KSW_ARGS, dbg);
 				else if (cls == 3) hipLaunchKernelGGL((k_ksw_extz2_lds<512, 5, 4, 288>), g, 64, 0, s, KSW_ARGS, dbg);
