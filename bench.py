@@ -39,9 +39,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: float) -> float:
+def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: float, d_small: float = None) -> float:
     """Per-launch algorithmic bytes of each overlap-stage kernel (SURVEY.md §8d:
-    B = 16.25 + 44 m + 20 d B/bp, split by the kernel that owns each term)."""
+    B = 16.25 + 44 m + 20 d B/bp, split by the kernel that owns each term).  k_chain_small is credited with the DP
+    elements of the groups IT processed (d_small, counted on the device: fg_overlap_batch.dp_elements_small) and with
+    none of the record bytes -- the other chaining kernels own the rest of the stage's bytes."""
     per_bp = {
         "k_probe": 0.25 + 16.0,                 # 2-bit read + one 16 B slot probe per k-mer
         "k_fill": m * (8.0 + 12.0),             # index entry read + hit write
@@ -49,6 +51,8 @@ def algorithmic_bytes(kernel: str, bp: float, m: float, d: float, ovl_per_bp: fl
         "k_chain": d * (12.0 + 8.0) + 44.0 * ovl_per_bp,  # hit read + score/backptr write + record
     }
     base = kernel.split("<")[0]
+    if base == "k_chain_small" and d_small is not None:
+        return d_small * (12.0 + 8.0) * bp
     if base.startswith("k_chain"):
         base = "k_chain"
     if base.startswith("k_sort"):       # k_sort_level / k_sort_wide / k_sort_lds share the sort's bytes
@@ -189,7 +193,8 @@ def main():
         dom_sec, dom_n = ktimes[dom_name]
         launches_per_step = max(1, dom_n // args.steps)
         avg_launch_s = dom_sec / max(1, dom_n)
-        alg = algorithmic_bytes(dom_name, res.query_bp, m, d, ovl) / launches_per_step
+        d_small = res.dp_elements_small / max(1, res.query_bp)
+        alg = algorithmic_bytes(dom_name, res.query_bp, m, d, ovl, d_small) / launches_per_step
         achieved = alg / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         # PMC traffic (FETCH_SIZE + WRITE_SIZE passes of tools/pmc_traffic.py) cannot be collected inside this
         # process; the committed figure is used only while it was measured on THESE kernel sources and THIS
@@ -239,6 +244,7 @@ def main():
             "roofline_stage": (dict(stages[dom_stage], stage=dom_stage, bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s") if dom_stage else None),
             "stages": stages,
             "work": {"seed_hits_per_bp": round(m, 4), "dp_elements_per_bp": round(d, 4),
+                     "dp_elements_small_per_bp": round(d_small, 4),
                      "overlaps": int(len(res.recs)), "device_ms_per_step": round(dev_s / args.steps * 1e3, 3),
                      "kernel_ms_per_step": {k: round(v[0] / args.steps * 1e3, 3) for k, v in
                                             sorted(ktimes.items(), key=lambda kv: -kv[1][0])},

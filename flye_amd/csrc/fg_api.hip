@@ -62,9 +62,12 @@ int guarded(fg_ctx* c, F f)
 	catch (const std::exception& e) { if (c) c->lastError = e.what(); rc = FG_ERR_HIP; }
 	// a call that failed half way may have left launches behind on either stream: nothing of the context's
 	// scratch is reused before they have drained
-	if (c && c->stream2) (void)hipStreamSynchronize(c->stream2);
-	if (c && c->stream3) (void)hipStreamSynchronize(c->stream3);
-	if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+	for (fg_ctx* x : {c, c ? c->lane2.get() : (fg_ctx*)nullptr})		// the second lane of fg_overlaps has streams of its own
+	{
+		if (x && x->stream2) (void)hipStreamSynchronize(x->stream2);
+		if (x && x->stream3) (void)hipStreamSynchronize(x->stream3);
+		if (x && x->stream) (void)hipStreamSynchronize(x->stream);
+	}
 	return rc;
 }
 

@@ -859,6 +859,14 @@ u32 fetchU32(fg_ctx* c, const u32* dptr)
 
 // All target groups of the batch -> dPrimFlag[g] = number of primaries (their (first, last,
 // chainLength, score) tuples at the head of the group's dCand region), dDpSize[g]
+// Groups of <= this many hits take the one-kernel path (k_chain_small); 0: none do (FG_CHAIN_FUSED=0, the three-kernel
+// path for all).  Its LDS: 28 B per hit of the largest group it takes; FG_FUSED_CAP for experiments.
+u32 fgChainSmallMax()
+{
+	if (getenv("FG_CHAIN_FUSED") && atoi(getenv("FG_CHAIN_FUSED")) == 0) return 0u;
+	return getenv("FG_FUSED_CAP") ? (u32)std::max(64, std::min(1024, atoi(getenv("FG_FUSED_CAP")))) : (u32)FIN_CAP_S;
+}
+
 void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits)
 {
@@ -890,10 +898,8 @@ void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u6
 	c->dTmp32.reserve(4 * hitCap + 16);
 	c->dCand.reserve(hitCap + 1);
 	const unsigned gridG = (unsigned)((nGroups + (u64)WG * LIST_ITEMS - 1) / ((u64)WG * LIST_ITEMS));
-	// groups of <= FIN_CAP_S hits take the one-kernel path (k_chain_small); FG_CHAIN_FUSED=0: the three-kernel path for all
-	const bool fused = !(getenv("FG_CHAIN_FUSED") && atoi(getenv("FG_CHAIN_FUSED")) == 0);
-	// (its LDS: 28 B per hit of the largest group it takes; FG_FUSED_CAP for experiments)
-	const u32 fusedMax = fused ? (getenv("FG_FUSED_CAP") ? (u32)std::max(64, std::min(1024, atoi(getenv("FG_FUSED_CAP")))) : (u32)FIN_CAP_S) : 0u;
+	const u32 fusedMax = fgChainSmallMax();
+	const bool fused = fusedMax != 0;
 	if (fused) c->dListFused.reserve(nGroups + 1);
 	HIP_CHECK(hipMemsetAsync(c->dListCnt.p, 0, 16, s));
 	{ ScopedK t(c->timer, "k_group_list");

@@ -367,6 +367,7 @@ struct fg_ctx {
 	PinnedBuf<u64> hMatches, hMatchOff;
 	PinnedBuf<u32> hMatchCnt;
 	DevBuf<char> dSortTasks, dSortBig;
+	DevBuf<unsigned long long> dSmallElems;	// DP elements in groups of <= 256 hits (work counter)
 	DevBuf<u32> dSortCnt;		// task counts of the sort's level loop, a row per level (fg_overlap.hip)
 	DevBuf<int> dEditScratch;
 	DevBuf<u32> dEditList;		// pairs queued for the bit-vector kernel (two lists)
@@ -633,6 +634,7 @@ void fgIndexLookupStructures(fg_ctx* c, bool bitsHoldSelection);
 void fgImportIndex(fg_ctx* c, u64 nKeys, const u64* keys, const u64* keyOff, u64 nEnt, const u64* entries, u64 nRep,
 				   const u64* repKeys, float sampleRate, int onDevice);
 // keyMode: 0 = 32-bit keys, 1 = packed 64-bit records (PK), 2 = 64-bit keys + values
+u32 fgChainSmallMax();
 void fgChainStage(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal, u64 nGroups, u64 nHits, int keyMode,
 				  int curBits);
 void fgEditDistances(fg_ctx* c, PrimRec* dPrims, u64 nPrim, int useHpc);

@@ -722,26 +722,33 @@ __global__ void k_group_fill(const u64* __restrict__ hitOff, HitKeyView<KT> hitK
 
 __global__ void k_prim_count(const u64* __restrict__ groupOff, const u32* __restrict__ primFlag,
 							 const u32* __restrict__ dpSize, u64* __restrict__ primCnt,
-							 u64* __restrict__ dpGroups, u64* __restrict__ dpElems)
+							 u64* __restrict__ dpGroups, u64* __restrict__ dpElems, const u64* __restrict__ groupStart,
+							 u64 nGroups, u64 nHits, u32 smallMax, unsigned long long* __restrict__ smallElems)
 {
-	__shared__ u32 sh[3][WG / 64];
+	__shared__ u32 sh[4][WG / 64];
 	const u32 q = blockIdx.x;
 	const u64 b = groupOff[q], e = groupOff[q + 1];
-	u32 c = 0, dg = 0, de = 0;
+	u32 c = 0, dg = 0, de = 0, ds = 0;
 	for (u64 i = b + threadIdx.x; i < e; i += WG)
 	{
 		c += primFlag[i];
 		const u32 d = dpSize[i];
 		dg += d != 0; de += d;
+		if (d && smallMax)		// the class k_group_list routes to k_chain_small: by the group's hits before the prefilter
+		{
+			const u64 n = (i + 1 < nGroups ? groupStart[i + 1] : nHits) - groupStart[i];
+			ds += n <= smallMax ? d : 0u;
+		}
 	}
-	for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); dg += __shfl_down(dg, o); de += __shfl_down(de, o); }
-	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = dg; sh[2][threadIdx.x >> 6] = de; }
+	for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); dg += __shfl_down(dg, o); de += __shfl_down(de, o); ds += __shfl_down(ds, o); }
+	if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = c; sh[1][threadIdx.x >> 6] = dg; sh[2][threadIdx.x >> 6] = de; sh[3][threadIdx.x >> 6] = ds; }
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		u64 t0 = 0, t1 = 0, t2 = 0;
-		for (int i = 0; i < WG / 64; ++i) { t0 += sh[0][i]; t1 += sh[1][i]; t2 += sh[2][i]; }
+		u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+		for (int i = 0; i < WG / 64; ++i) { t0 += sh[0][i]; t1 += sh[1][i]; t2 += sh[2][i]; t3 += sh[3][i]; }
 		primCnt[q] = t0; dpGroups[q] = t1; dpElems[q] = t2;
+		if (t3) atomicAdd(smallElems, (unsigned long long)t3);
 	}
 }
 
@@ -997,7 +1004,7 @@ static void probePartitioned(fg_ctx* c, u32 nq, const u64* localOff, const u64* 
 // Device part of one chunk of queries [qa, qb): seed collection -> sort -> groups ->
 // chaining -> (edit distance) -> compacted primaries in c->hPrim / offsets in c->hOff.
 // Returns false (nothing done) when the chunk's hits exceed the budget and it can be split.
-struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems, nMatchSlots; };
+struct ChunkResult { u64 nPrim, nHits, dpGroups, dpElems, dpElemsSmall, nMatchSlots; };
 
 // Probe step of one chunk of queries [qa, qb) (bounded by the k-mer budget): every query k-mer's table value in
 // c->dProbe, hits / repetitive positions per query in c->dCntA / c->dCntB; hitsPerQuery = the former on the host.
@@ -1127,9 +1134,11 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	  else hipLaunchKernelGGL(k_group_fill<u64>, nq, WG, 0, s, c->dHitOff.p, hk64, c->dGroupOff.p, c->dGroupStart.p,
 							  c->dGroupQuery.p, c->dGroupExt.p, c->dGroupFirstCur.p, c->dGroupLastCur.p); }
 	fgChainStage(c, p, forceLocal, nGroups, nHits, keyMode, curBits);
+	c->dSmallElems.reserve(1);
+	HIP_CHECK(hipMemsetAsync(c->dSmallElems.p, 0, 8, s));
 	{ ScopedK t(c->timer, "k_prim_count");
 	  hipLaunchKernelGGL(k_prim_count, nq, WG, 0, s, c->dGroupOff.p, c->dPrimFlag.p, c->dDpSize.p, c->dPrimCnt.p,
-						 c->dDpGroups.p, c->dDpElems.p); }
+						 c->dDpGroups.p, c->dDpElems.p, c->dGroupStart.p, nGroups, nHits, fgChainSmallMax(), c->dSmallElems.p); }
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dPrimCnt.p, c->dPrimOff.p, nq); }
 	const u64 nPrim = fetchScalar(c, c->dPrimOff.p + nq);
@@ -1169,11 +1178,12 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 		HIP_CHECK(hipStreamSynchronize(s));		// copies of earlier chunks may still be on their way into the old buffer
 		c->hPrim.reserveKeep((primBase + nPrim + 1) * sizeof(PrimRec), primBase * sizeof(PrimRec));
 	}
-	c->hOff.reserve(3 * (size_t)(nq + 1));
+	c->hOff.reserve(3 * (size_t)(nq + 1) + 1);
 	{ ScopedK t(c->timer, "copy_results_d2h");
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p, c->dPrimOff.p, (nq + 1) * 8ULL, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + (nq + 1), c->dDpGroups.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 2 * (size_t)(nq + 1), c->dDpElems.p, nq * 8ULL, hipMemcpyDeviceToHost, s));
+	  HIP_CHECK(hipMemcpyAsync(c->hOff.p + 3 * (size_t)(nq + 1), c->dSmallElems.p, 8, hipMemcpyDeviceToHost, s));
 	  HIP_CHECK(hipEventRecord(c->evOff, s));
 	  // the records in pieces, an event behind each: the caller does not wait for them here (the host shim's
 	  // threads wait for the piece they read)
@@ -1191,6 +1201,7 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	if (keepAln) HIP_CHECK(hipStreamSynchronize(s));		// the match lists are read by the caller right away
 	res->nPrim = nPrim;
 	res->dpGroups = 0; res->dpElems = 0;
+	res->dpElemsSmall = c->hOff.p[3 * (size_t)(nq + 1)];
 	for (u32 i = 0; i < nq; ++i) { res->dpGroups += c->hOff.p[(nq + 1) + i]; res->dpElems += c->hOff.p[2 * (size_t)(nq + 1) + i]; }
 }
 
@@ -1334,7 +1345,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 	std::vector<const PrimRec*> primPtr(nq, nullptr);	// primary j (counted over the call) of query qi = primPtr[qi][j]
 	std::vector<u64> hitsPerQuery;
 	u64 nPrim = 0;
-	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0;
+	out->seed_hits = 0; out->dp_groups = 0; out->dp_elements = 0; out->dp_elements_small = 0;
 	const int nLanes = getenv("FG_LANES") ? std::max(1, std::min(2, atoi(getenv("FG_LANES")))) : 2;
 	const u64 laneMinHits = getenv("FG_LANE_MIN_HITS") ? strtoull(getenv("FG_LANE_MIN_HITS"), nullptr, 10) : (48ULL << 20);
 	const u32 laneSplit = getenv("FG_LANE_SPLIT") ? (u32)std::max(2, atoi(getenv("FG_LANE_SPLIT"))) : 4u;
@@ -1464,6 +1475,7 @@ void fgOverlaps(fg_ctx* c, const fg_detector_params* p, const u32* queryIds, u32
 				mOff.push_back(mData.size());
 			}
 		out->seed_hits += sr.cr.nHits; out->dp_groups += sr.cr.dpGroups; out->dp_elements += sr.cr.dpElems;
+		out->dp_elements_small += sr.cr.dpElemsSmall;
 		nPrim += sr.cr.nPrim;
 	}
 	HIP_CHECK(hipEventRecord(evB, s));

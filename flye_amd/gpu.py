@@ -75,6 +75,7 @@ class OverlapBatch(C.Structure):
                 ("div_stats", C.c_void_p), ("n_matches", C.c_uint64), ("match_off", C.c_void_p),
                 ("matches", C.c_void_p), ("needs_trim", C.c_void_p), ("query_bp", C.c_uint64), ("query_kmers", C.c_uint64),
                 ("seed_hits", C.c_uint64), ("dp_groups", C.c_uint64), ("dp_elements", C.c_uint64),
+                ("dp_elements_small", C.c_uint64),
                 ("device_seconds", C.c_double), ("owner_", C.c_void_p)]
 
 
@@ -223,6 +224,7 @@ class OverlapResult:
         self.needs_trim = arena.view(b.needs_trim, C.c_uint8, b.n_recs, np.uint8) if b.needs_trim else None
         self.query_bp, self.query_kmers = b.query_bp, b.query_kmers
         self.seed_hits, self.dp_groups, self.dp_elements = b.seed_hits, b.dp_groups, b.dp_elements
+        self.dp_elements_small = b.dp_elements_small
         self.device_seconds = b.device_seconds
 
     def of(self, i):

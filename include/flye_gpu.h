@@ -260,6 +260,7 @@ struct fg_overlap_batch {
 	uint8_t* needs_trim;           /* n_recs */
 	/* work counters of this call (for the roofline's m and d) */
 	uint64_t query_bp, query_kmers, seed_hits, dp_groups, dp_elements;
+	uint64_t dp_elements_small;    /* of dp_elements: in groups of <= 256 hits (the one-kernel chaining path) */
 	double   device_seconds;       /* HIP-event time of the whole call */
 	void*    owner_;               /* library arena; release with fg_release_batch */
 };

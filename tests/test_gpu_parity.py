@@ -116,6 +116,7 @@ def test_against_oracle_variants(built, seed, kind, opts):
     assert (gres.query_kmers, gres.seed_hits) == (ores.query_kmers, ores.seed_hits)
     if not opts.get("max_overlaps"):   # with a limit the reference stops visiting groups early
         assert (gres.dp_groups, gres.dp_elements) == (ores.dp_groups, ores.dp_elements)
+        assert 0 <= gres.dp_elements_small <= gres.dp_elements      # the one-kernel chaining class's share (bench's roofline)
     # batch invariance: any sub-batch gives the same per-read lists
     sub = q[5:40:3]
     part = det.getSeqOverlapsBatch(sub, forceLocal=opts.get("force_local", False),
