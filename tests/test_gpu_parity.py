@@ -229,13 +229,20 @@ def _median3_killer(n):
     return a
 
 
-@pytest.mark.parametrize("stream_max", [None, 600, 10 ** 9])
+@pytest.mark.parametrize("stream_max", [None, 600, 10 ** 9, "mid1024", "mid8192", "many"])
 def test_device_sort_equals_std_sort(built, monkeypatch, stream_max):
     """k_sort_hits on its own: tie-heavy, patterned and adversarial inputs must come
-    out in exactly the permutation std::sort produces (heapsort fallback included)."""
+    out in exactly the permutation std::sort produces (heapsort fallback included).  Every tier and form of the
+    level loop: the streamed and the closed-form partition at any piece size, the in-LDS workgroup tier
+    (k_sort_mid, FG_SORT_MID_MAX) and the many-pieces rule of large chunks forced on at this size."""
     from flye_amd import gpu
     from oracle import oracle as O
-    if stream_max is not None:      # which partition form the level kernel uses above the LDS piece size
+    if isinstance(stream_max, str) and stream_max.startswith("mid"):
+        monkeypatch.setenv("FG_SORT_MID_MAX", stream_max[3:])
+    elif stream_max == "many":
+        monkeypatch.setenv("FG_SORT_MANY_MIN", "2")
+        monkeypatch.setenv("FG_SORT_STREAM_MANY", "50000")
+    elif stream_max is not None:      # which partition form the level kernel uses above the LDS piece size
         monkeypatch.setenv("FG_SORT_STREAM_MAX", str(stream_max))
     rng = np.random.default_rng(7)
     segs = []
@@ -878,6 +885,27 @@ def test_partitioned_probes_are_invisible(built, golden_cases, monkeypatch, name
                                   maxOverlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
     assert "k_probe_emit" in ctx.kernel_times()
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,env", [("raw_pb", {"FG_SORT_MID_MAX": "2048"}), ("hifi", {"FG_SORT_MID_MAX": "4096"}),
+                                      ("raw_ont_rc", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"})])
+def test_sort_tiers_are_invisible(built, golden_cases, monkeypatch, name, env):
+    """The hit sort's optional tiers inside the overlap stage itself (32-bit keys): the in-LDS workgroup tier
+    k_sort_mid and the many-pieces streaming rule, forced on at golden-case size: same records."""
+    case = golden_cases[name]
+    rs = golden_reads(case)
+    from flye_amd import config
+    cfg = config.preset(case["preset"])
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx, vi, st, det = _gpu_setup(rs, cfg)
+    det.p.max_divergence = bits_to_float(case["max_div_bits"])
+    res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
+                                  maxOverlaps=case.get("max_overlaps", 0))
+    assert res.lines() == golden_lines(name)
+    if "FG_SORT_MID_MAX" in env:
+        assert "k_sort_mid" in ctx.kernel_times()
     ctx.close()
 
 
