@@ -512,6 +512,90 @@ k_chain_dp(ChainParams P, const u32* __restrict__ list, u32 nList, u64 nGroups, 
 	else dp_group<false>(P.k, P.maxJump, n, gCur + g0, gExt + g0, gScore + g0, gBack + g0, ringC, ringE, ringS);
 }
 
+// ---- score order without the introsort emulation, where it cannot matter ------------------------------------------
+// The backtracking visits the elements in descending score order and skips those without a back pointer wherever they
+// stand (overlap.cpp:331-340).  So only the RELATIVE order of the elements that have one matters, and that order is
+// the same under any sorting algorithm unless two of them share a score: 3 groups in 4 of the bench workload have no
+// such tie (oracle, FO_STATS4).  Those take a bitonic network over (score, index) words held in registers -- ~100
+// instructions for <= 64 hits against the ~10x of the partition-by-partition emulation; a group with a tie among its
+// live elements (found by one neighbour compare on the sorted words) takes the emulation as before.
+// R words per lane, element e = r * 64 + lane.  Returns the number of live elements (their indices, in visiting order,
+// in oval[0 .. nLive)), or -1 when the order depends on std::sort's tie handling (nothing written).
+template <int R>
+__device__ __forceinline__ i32 fast_score_order(const i32 n, const i32* score, const i32* back, u32* oval)
+{
+	const int lane = threadIdx.x & 63;
+	u32 v[R];
+	bool wide = false;
+#pragma unroll
+	for (int r = 0; r < R; ++r)
+	{
+		const i32 e = r * 64 + lane;
+		const bool live = e < n && back[e] != -1;
+		const i32 sc = live ? score[e] : 0;
+		wide |= live && (u32)sc >= (1u << 22);	// (index: 10 bits; scores this large are not seen: positions have 24 bits)
+		v[r] = live ? ((u32)((1 << 22) - 1 - sc) << 10) | (u32)e : 0xFFFFFFFFu;
+	}
+	if (__builtin_amdgcn_ballot_w64(wide)) return -1;
+#pragma unroll
+	for (int k = 2; k <= 64 * R; k <<= 1)
+	{
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1)
+		{
+			if (j >= 64)
+			{
+#pragma unroll
+				for (int r = 0; r < R; ++r)
+				{
+					const int rp = r ^ (j >> 6);
+					if (rp > r)
+					{
+						const bool asc = ((r * 64) & k) == 0;	// k > 64 here: the bit sits in r; k == 64 R: always ascending
+						const u32 lo = min(v[r], v[rp]), hi = max(v[r], v[rp]);
+						v[r] = asc ? lo : hi; v[rp] = asc ? hi : lo;
+					}
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int r = 0; r < R; ++r)
+				{
+					const u32 o = (u32)__shfl_xor((int)v[r], j);
+					const bool asc = (((r * 64 + lane) & k) == 0);
+					const bool lower = (lane & j) == 0;
+					v[r] = (asc == lower) ? min(v[r], o) : max(v[r], o);
+				}
+			}
+		}
+	}
+	// sorted ascending: live elements first (descending score), the others (all ones) behind them
+	bool tie = false;
+	i32 nLive = 0;
+#pragma unroll
+	for (int r = 0; r < R; ++r)
+	{
+		u32 nx = (u32)__shfl_down((int)v[r], 1);
+		const u32 first = r + 1 < R ? (u32)__builtin_amdgcn_readlane((int)v[r + 1 < R ? r + 1 : r], 0) : 0xFFFFFFFFu;
+		if (lane == 63) nx = first;
+		tie |= nx != 0xFFFFFFFFu && (nx >> 10) == (v[r] >> 10);
+		nLive += __popcll(__builtin_amdgcn_ballot_w64(v[r] != 0xFFFFFFFFu));
+	}
+	if (__builtin_amdgcn_ballot_w64(tie)) return -1;
+#pragma unroll
+	for (int r = 0; r < R; ++r)
+		if (v[r] != 0xFFFFFFFFu) oval[r * 64 + lane] = v[r] & 1023u;
+	return nLive;
+}
+
+// (The groups that live in global memory -- more than 256 hits -- keep the emulation: a stable LSD radix sort of their
+// live (score, index) pairs with LDS counters, also with four tiles' loads in flight and the next pass's histogram
+// taken while scattering, was measured no faster than the emulation it would replace -- HiFi 30x, 420 k such groups
+// of ~1500 hits: 26 ms for the 77 % of groups without a tie against ~33 ms before, and the bench workload's
+// k_chain_finish<global> went from 5.9 to 6.6 ms -- its scattered 4-byte stores are what it waits for.  The bitonic
+// network on words in LDS for groups of 257..1024 hits: HiFi 87 -> 82 ms, bench workload 5.7 -> 6.3 ms: dropped too.)
+
 // ---- finish ------------------------------------------------------------------------------
 // One group's backtracking stage on one wave (the body of k_chain_finish and of the fused small-group kernel):
 // score / back: the DP's arrays (LDS when USE_LDS, else the group's global ones; back is consumed), okey / oval:
@@ -525,9 +609,21 @@ __device__ __forceinline__ void finish_group(const ChainParams& P, const i32 n, 
 	const int lane = threadIdx.x & 63;
 	const int k = P.k;
 	// chain starts in descending score order, ties as std::sort leaves them (overlap.cpp:331-334)
-	for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
+	i32 nOrder = -1;		// entries of oval to visit
+	if (USE_LDS && !(P.ablate & 64))
+	{
+		if (n <= 64) nOrder = fast_score_order<1>(n, score, back, oval);
+		else if (n <= 128) nOrder = fast_score_order<2>(n, score, back, oval);
+		else if (n <= 256) nOrder = fast_score_order<4>(n, score, back, oval);
+	}
+	const bool exact = nOrder < 0;
+	if (exact)
+	{
+		for (i32 i = lane; i < n; i += 64) { okey[i] = (u32)(0x7fffffff - score[i]); oval[i] = (u32)i; }
+		nOrder = n;
+	}
 	wsort::wave_mem_fence();
-	if (!(P.ablate & 2))
+	if (exact && !(P.ablate & 2))
 	{
 		if (USE_LDS)
 			wsort::wave_sort<u32, unsigned short>(okey, oval, n, plLds, plLds + n, stack, small);
@@ -587,10 +683,10 @@ __device__ __forceinline__ void finish_group(const ChainParams& P, const i32 n, 
 	const bool inMemory = !USE_LDS && !(BT_CAP > 0 && n <= BT_CAP);
 	// (LDS-resident groups keep the plain lane-0 walk below: their chains are short and jump further, the
 	// window reloads cost more than the LDS hops -- 9.9 against 7.4 ms on the bench workload)
-	for (i32 oi0 = 0; inMemory && oi0 < n; oi0 += 64)
+	for (i32 oi0 = 0; inMemory && oi0 < nOrder; oi0 += 64)
 	{
 		flushWin();		// the screening below reads the array itself
-		const bool in = oi0 + lane < n;
+		const bool in = oi0 + lane < nOrder;
 		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
 		i32 bk = -1;
 		if (in)
@@ -630,9 +726,9 @@ __device__ __forceinline__ void finish_group(const ChainParams& P, const i32 n, 
 			}
 		}
 	}
-	for (i32 oi0 = 0; !inMemory && oi0 < n; oi0 += 64)
+	for (i32 oi0 = 0; !inMemory && oi0 < nOrder; oi0 += 64)
 	{
-		const bool in = oi0 + lane < n;
+		const bool in = oi0 + lane < nOrder;
 		const i32 st = in ? (i32)oval[oi0 + lane] : 0;
 		const i32 bk = in ? back[st] : -1;
 		u64 m = __builtin_amdgcn_ballot_w64(bk != -1);

@@ -841,6 +841,33 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 		const std::vector<int32_t>& sc = S.score;
 		std::sort(S.order.begin(), S.order.end(), [&sc](size_t a, size_t b) { return sc[a] > sc[b]; });
 
+		if (getenv("FO_STATS5"))
+		{
+			// would the visiting order ever have to choose between two elements of equal score that are BOTH still
+			// unconsumed when their score comes up?  (dry run on a copy of the back pointers)
+			static std::atomic<unsigned long long> H[4];	// groups, elems, ambiguous groups, their elems
+			std::vector<int32_t> bk(S.back.begin(), S.back.begin() + n);
+			bool amb = false;
+			for (int32_t a = 0; a < n && !amb; )
+			{
+				int32_t b = a;
+				while (b + 1 < n && sc[S.order[b + 1]] == sc[S.order[a]]) ++b;
+				int alive = 0;
+				for (int32_t t = a; t <= b; ++t) alive += bk[S.order[t]] != -1;
+				if (alive >= 2) amb = true;
+				for (int32_t t = a; t <= b; ++t)
+				{
+					int32_t pos = (int32_t)S.order[t];
+					if (bk[pos] == -1) continue;
+					while (pos != -1) { const int32_t np = bk[pos]; bk[pos] = -1; pos = np; }
+				}
+				a = b + 1;
+			}
+			H[0] += 1; H[1] += n; if (amb) { H[2] += 1; H[3] += n; }
+			if ((H[0] & 0x3FFF) == 0)
+				fprintf(stderr, "groups %llu (%llu el): two live elements of one score at visiting time in %llu (%llu el)\n",
+						(unsigned long long)H[0], (unsigned long long)H[1], (unsigned long long)H[2], (unsigned long long)H[3]);
+		}
 		std::vector<Cand> cands;
 		for (size_t oi = 0; oi < S.order.size(); ++oi)
 		{
