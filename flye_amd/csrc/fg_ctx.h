@@ -375,8 +375,6 @@ struct fg_ctx {
 	DevBuf<u64> dEditSlab;		// per-block string planes + delta planes of the bit-vector kernel
 	PinnedBuf<char> hPrim;
 	PinnedBuf<u64> hOff;
-	PinnedBuf<u32> hSortErr;	// k_sort_mid's error word, copied behind the kernel; read after the next wait on the stream
-	bool sortErrPending = false;
 	PinnedBuf<u64> hScalar;		// staging of the counts the host reads between kernels (pinned: no bounce buffer)
 	// host shim: worker threads and result-sized scratch kept between calls
 	ShimPool shimPool;

@@ -384,12 +384,11 @@ template <> struct ValPtr<PK> {
 };
 
 // block-aggregated append (one atomic per list and block).  Lists: big (one wave per task in
-// k_sort_level), wide (> wideMin elements: a whole workgroup per task, k_sort_wide), mid (<= midMax: every further
-// level by one workgroup in LDS, k_sort_mid), small (<= SORT_CAP: k_sort_lds).  counts: [0] big, [2] wide of the
-// next level; smallCnt[0] small, smallCnt[1] mid (all levels together).
+// k_sort_level), wide (> wideMin elements: a whole workgroup per task, k_sort_wide), small
+// (<= SORT_CAP: k_sort_lds).  counts: [0] big, [2] wide of the next level; smallCnt: small pieces of all levels.
 struct SortLists {
-	SortTask* big; SortTask* wide; SortTask* small; SortTask* mid;
-	u32 wideMin, midMax, smallCap;
+	SortTask* small;
+	u32 wideMin, smallCap;
 	// A level with >= manyMin pieces has enough one-wave tasks in flight to hide the streamed partition's serial chain,
 	// and that form moves 12 B per hit against the closed form's ~30: there pieces of up to streamMany hits stay
 	// one-wave tasks and are streamed; a level with few pieces uses streamMax / wideMin (closed form, whole workgroups)
@@ -406,34 +405,27 @@ __device__ __forceinline__ void sort_route(const SortTask& t, bool valid, const 
 										   SortTask* __restrict__ wide, u32* __restrict__ counts /* [0] big, [2] wide */,
 										   u32* __restrict__ smallCnt)
 {
-	__shared__ u32 wcnt[4][WG / 64];
-	__shared__ u32 base[4];
+	__shared__ u32 wcnt[3][WG / 64];
+	__shared__ u32 base[3];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const bool isWide = valid && t.n > wideMin && t.n > SORT_CAP;
+	const bool isBig = valid && t.n > SORT_CAP && !isWide;
 	const bool isSmall = valid && t.n >= 2 && t.n <= SORT_CAP;
-	const bool isMid = valid && t.n > SORT_CAP && t.n <= L.midMax;
-	const bool isWide = valid && t.n > wideMin && t.n > SORT_CAP && !isMid;
-	const bool isBig = valid && t.n > SORT_CAP && !isWide && !isMid;
-	const u64 mB = __ballot(isBig), mS = __ballot(isSmall), mW = __ballot(isWide), mM = __ballot(isMid);
-	if (lane == 0)
-	{
-		wcnt[0][wv] = (u32)__popcll(mB); wcnt[1][wv] = (u32)__popcll(mS); wcnt[2][wv] = (u32)__popcll(mW);
-		wcnt[3][wv] = (u32)__popcll(mM);
-	}
+	const u64 mB = __ballot(isBig), mS = __ballot(isSmall), mW = __ballot(isWide);
+	if (lane == 0) { wcnt[0][wv] = (u32)__popcll(mB); wcnt[1][wv] = (u32)__popcll(mS); wcnt[2][wv] = (u32)__popcll(mW); }
 	__syncthreads();
-	if (threadIdx.x < 4)
+	if (threadIdx.x < 3)
 	{
 		u32 tot = 0;
 		for (int i = 0; i < WG / 64; ++i) tot += wcnt[threadIdx.x][i];
-		u32* cnt = threadIdx.x == 1 ? smallCnt : (threadIdx.x == 3 ? smallCnt + 1 : &counts[threadIdx.x]);
-		base[threadIdx.x] = tot ? atomicAdd(cnt, tot) : 0u;
+		base[threadIdx.x] = tot ? atomicAdd(threadIdx.x == 1 ? smallCnt : &counts[threadIdx.x], tot) : 0u;
 	}
 	__syncthreads();
 	const u64 below = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-	u32 oB = base[0], oS = base[1], oW = base[2], oM = base[3];
-	for (int i = 0; i < wv; ++i) { oB += wcnt[0][i]; oS += wcnt[1][i]; oW += wcnt[2][i]; oM += wcnt[3][i]; }
+	u32 oB = base[0], oS = base[1], oW = base[2];
+	for (int i = 0; i < wv; ++i) { oB += wcnt[0][i]; oS += wcnt[1][i]; oW += wcnt[2][i]; }
 	if (isBig) big[oB + __popcll(mB & below)] = t;
 	if (isWide) wide[oW + __popcll(mW & below)] = t;
-	if (isMid) L.mid[oM + __popcll(mM & below)] = t;		// pieces > SORT_CAP are disjoint: the list holds them all
 	if (isSmall)
 	{
 		const u32 slot = oS + __popcll(mS & below);
@@ -549,11 +541,10 @@ __global__ void k_sort_route(const SortTask* __restrict__ children, const u32* _
 
 template <class KT>
 __global__ void __launch_bounds__(SORT_LDS_WAVES * 64)
-k_sort_lds(const SortTask* __restrict__ tasks, u32 firstTask, u32 nTasks, const u32* __restrict__ endPtr, u32 endCap,
+k_sort_lds(const SortTask* __restrict__ tasks, u32 nTasks,
 		   KT* __restrict__ hitKey, u32* __restrict__ hitVal, int curBits, u64 narrowMax,
 		   u32* __restrict__ posScratch, u64 nHits)
 {
-	// tasks [firstTask, nTasks), or -- endPtr given -- [firstTask, min(*endPtr, endCap)): the pieces k_sort_mid handed on
 	// the LDS piece always holds 32-bit keys (12 B per hit with the position scratch)
 	__shared__ u32 sK[SORT_LDS_WAVES][SORT_CAP];
 	__shared__ u32 sV[SORT_LDS_WAVES][SORT_CAP];
@@ -562,8 +553,7 @@ k_sort_lds(const SortTask* __restrict__ tasks, u32 firstTask, u32 nTasks, const 
 	__shared__ int small[SORT_LDS_WAVES][3 * 8];
 	const int wv = threadIdx.x >> 6;
 	const int lane = threadIdx.x & 63;
-	if (endPtr) { nTasks = fg_uni(*endPtr); nTasks = nTasks < endCap ? nTasks : endCap; }
-	for (u32 ti = firstTask + blockIdx.x * SORT_LDS_WAVES + wv; ti < nTasks; ti += gridDim.x * SORT_LDS_WAVES)
+	for (u32 ti = blockIdx.x * SORT_LDS_WAVES + wv; ti < nTasks; ti += gridDim.x * SORT_LDS_WAVES)
 	{
 	SortTask t = tasks[ti];
 	t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
@@ -681,264 +671,6 @@ k_sort_lds(const SortTask* __restrict__ tasks, u32 firstTask, u32 nTasks, const 
 	wsort::wave_sort<KT, u32>(K, V, n, posScratch + t.start, posScratch + nHits + t.start, stack[wv], small[wv], 0,
 							  (int)t.depth);
 	}
-	}
-}
-
-// ---- pieces of SORT_CAP < n <= midMax hits: every remaining level of the introsort by ONE workgroup, in LDS --------
-// The piece is loaded once, its waves take partitions from a shared stack (one wave = one Hoare partition, the larger
-// half goes back on the stack, the wave goes on with the smaller one), pieces of <= SORT_CAP hits are finished by the
-// wave that meets them exactly as k_sort_lds would, and the piece is written back once -- the levels between midMax and
-// SORT_CAP cost no global-memory pass and no launch.  A partition's result depends only on its piece, so the order in
-// which the waves take them does not matter.
-#ifndef SORT_MID_WAVES
-#define SORT_MID_WAVES 8
-#endif
-#define SORT_MID_QCAP 96		// shared stack entries (a full stack: the wave keeps the piece on its private stack)
-#define SORT_MID_PRIV 24		// private stack entries (larger half waits, smaller one continues: <= log2 n deep)
-template <class KT> struct MidBytes { static constexpr int perHit = (int)sizeof(KT) + 4; };
-template <> struct MidBytes<PK> { static constexpr int perHit = 8; };
-// LDS of one workgroup: the piece (dynamic) + the waves' position lists and stacks and the shared stack (static; they are
-// declared as LDS arrays so that every access to the lock and the counters is a DS instruction, in order per wave)
-static constexpr size_t SORT_MID_STATIC = (size_t)SORT_MID_WAVES * (2 * SORT_CAP * 2 + (3 * 40 + 3 * 8 + 3 * SORT_MID_PRIV) * 4) +
-										  (8 + 3 * SORT_MID_QCAP) * 4;
-static size_t sortMidLdsBytes(int perHit, u32 cap) { return (size_t)cap * perHit + SORT_MID_STATIC + 256; }
-
-template <class KT>
-__global__ void __launch_bounds__(SORT_MID_WAVES * 64)
-k_sort_mid(const SortTask* __restrict__ tasks, u32 nTasks, u32* __restrict__ ticket, u32 cap,
-		   KT* __restrict__ hitKey, u32* __restrict__ hitVal, int curBits, u64 narrowMax,
-		   SortTask* __restrict__ handOn, u32 handOnCap, u32* __restrict__ handOnCnt, u32* __restrict__ errWord)
-{
-	extern __shared__ __align__(16) unsigned char midLds[];
-	typedef typename ValPtr<KT>::type VP;
-	KT* sK = (KT*)midLds;
-	u32* sVraw = (u32*)(midLds + (size_t)cap * sizeof(KT));
-	VP sV = ValPtr<KT>::at(sVraw, 0);
-	__shared__ unsigned short sPL[SORT_MID_WAVES][SORT_CAP], sPR[SORT_MID_WAVES][SORT_CAP];
-	__shared__ int sStk[SORT_MID_WAVES][3 * 40], sSstk[SORT_MID_WAVES][3 * 8], sPriv[SORT_MID_WAVES][3 * SORT_MID_PRIV];
-	__shared__ int ctl[8];				// [0] stack top, [1] lock, [2] hits not yet final, [3] task of this round, [4] give up
-	__shared__ int q[3 * SORT_MID_QCAP];
-	const int wv = wsort::uni((int)(threadIdx.x >> 6));
-	const int lane = threadIdx.x & 63;
-	unsigned short* PL = sPL[wv];
-	unsigned short* PR = sPR[wv];
-	int* stk = sStk[wv];				// wave_sort's own stack
-	int* sstk = sSstk[wv];
-	int* priv = sPriv[wv];				// this wave's waiting pieces
-	// every wait in here is bounded: a wave that waits longer than any piece can take raises ctl[4], all waves leave
-	// the piece as it is and the host reports the error word (never seen; a kernel that could spin for ever is not shipped)
-	auto lock = [&]() -> bool
-	{
-		for (int spin = 0; spin < (1 << 22); ++spin)
-		{
-			if (atomicCAS(&ctl[1], 0, 1) == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); return true; }
-			__builtin_amdgcn_s_sleep(1);
-		}
-		__hip_atomic_store(&ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		return false;
-	};
-	auto unlock = [&]() { __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
-	for (;;)
-	{
-		if (threadIdx.x == 0) ctl[3] = (int)atomicAdd(ticket, 1u);
-		__syncthreads();
-		const u32 ti = (u32)wsort::uni(ctl[3]);
-		if (ti >= nTasks) break;
-		SortTask t = tasks[ti];
-		t.start = fg_uni(t.start); t.n = fg_uni(t.n); t.depth = fg_uni(t.depth);
-		KT* K = hitKey + t.start;
-		VP V = ValPtr<KT>::at(hitVal, t.start);
-		const int n = (int)t.n;
-		for (int i = threadIdx.x; i < n; i += SORT_MID_WAVES * 64) { sK[i] = K[i]; sV[i] = V[i]; }
-		if (threadIdx.x == 0) { q[0] = 0; q[1] = n; q[2] = (int)t.depth; ctl[0] = 1; ctl[1] = 0; ctl[2] = n; ctl[4] = 0; }
-		__syncthreads();
-		int np = 0;		// pieces on the private stack
-		int idle = 0;
-		for (;;)
-		{
-			int first = 0, last = 0, depth = 0, state = 0;		// state: 0 nothing to take yet, 1 took a piece, 2 all done
-			if (np > 0)
-			{
-				--np;
-				first = wsort::uni(priv[3 * np]); last = wsort::uni(priv[3 * np + 1]); depth = wsort::uni(priv[3 * np + 2]);
-				state = 1;
-			}
-			else
-			{
-				if (lane == 0)
-				{
-					if (__hip_atomic_load(&ctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || !lock()) state = 2;
-					else
-					{
-						const int top = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						if (top > 0)
-						{
-							first = q[3 * (top - 1)]; last = q[3 * (top - 1) + 1]; depth = q[3 * (top - 1) + 2];
-							__hip_atomic_store(&ctl[0], top - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							state = 1;
-						}
-						else if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) state = 2;
-						unlock();
-					}
-				}
-				state = wsort::uni(state); first = wsort::uni(first); last = wsort::uni(last); depth = wsort::uni(depth);
-				if (state == 2) break;
-				if (state == 0)
-				{
-					if (++idle > (1 << 22))		// ~ 1 s of polling: no piece of <= 16 k hits takes that long
-					{
-						if (lane == 0) __hip_atomic_store(&ctl[4], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						break;
-					}
-					__builtin_amdgcn_s_sleep(8);
-					continue;
-				}
-				idle = 0;
-				wsort::wave_mem_fence();		// the piece as its producer left it
-			}
-			for (;;)		// one piece: partitions until what is left is a leaf
-			{
-				const int size = last - first;
-				int finished = 0;
-				if (size <= SORT_CAP)
-				{
-					if (size >= 2)
-					{
-						bool sorted = true;
-						if constexpr (sizeof(KT) == 4)
-							wsort::wave_sort<u32, unsigned short>((u32*)sK, sVraw, size, PL, PR, stk, sstk, first, depth);
-						else
-						{
-							// 64-bit keys / packed records: narrowed to 32-bit keys relative to the leaf's minimum where it lies
-							// (the two halves of its own LDS bytes), as k_sort_lds does
-							constexpr bool PACKED = std::is_same<KT, PK>::value;
-							const u64 vmask = (1ULL << FG_PK_VALBITS) - 1;
-							const u64 lowMask = curBits ? (1ULL << curBits) - 1 : 0;
-							u64* P = (u64*)(sK + first);
-							u64 pk[(SORT_CAP + 63) / 64];
-							u64 mn = ~0ULL, mx = 0;
-#pragma unroll
-							for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
-							{
-								const int i = j * 64 + lane;
-								u64 rec = i < size ? P[i] : 0;
-								u64 key;
-								if (PACKED) key = rec >> FG_PK_VALBITS;
-								else { if (curBits) rec = ((rec >> 32) << curBits) | (rec & 0xFFFFFFFFULL); key = rec; }
-								pk[j] = rec;
-								if (i < size) { mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
-							}
-							for (int o = 32; o > 0; o >>= 1)
-							{
-								const u64 a = wsort::shflk(mn, lane ^ o), b = wsort::shflk(mx, lane ^ o);
-								mn = a < mn ? a : mn; mx = b > mx ? b : mx;
-							}
-							mn = fg_uni(mn); mx = fg_uni(mx);
-							if (mx - mn <= narrowMax)
-							{
-								u32* k32 = (u32*)P;
-								u32* v32 = PACKED ? k32 + size : sVraw + first;
-								wsort::wave_mem_fence();
-#pragma unroll
-								for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
-								{
-									const int i = j * 64 + lane;
-									if (i < size)
-									{
-										if (PACKED) { k32[i] = (u32)((pk[j] >> FG_PK_VALBITS) - mn); v32[i] = (u32)(pk[j] & vmask); }
-										else k32[i] = (u32)(pk[j] - mn);
-									}
-								}
-								wsort::wave_mem_fence();
-								wsort::wave_sort<u32, unsigned short>(k32, v32, size, PL, PR, stk, sstk, 0, depth);
-								u32 rk[(SORT_CAP + 63) / 64], rv[(SORT_CAP + 63) / 64];
-#pragma unroll
-								for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
-								{
-									const int i = j * 64 + lane;
-									rk[j] = i < size ? k32[i] : 0u;
-									rv[j] = (PACKED && i < size) ? v32[i] : 0u;
-								}
-								wsort::wave_mem_fence();
-#pragma unroll
-								for (int j = 0; j < (SORT_CAP + 63) / 64; ++j)
-								{
-									const int i = j * 64 + lane;
-									if (i < size)
-									{
-										const u64 p = (u64)rk[j] + mn;
-										if (PACKED) P[i] = (p << FG_PK_VALBITS) | (u64)rv[j];
-										else P[i] = curBits ? (((p >> curBits) << 32) | (p & lowMask)) : p;
-									}
-								}
-								wsort::wave_mem_fence();
-							}
-							else sorted = false;
-						}
-						if (!sorted && lane == 0)
-						{
-							// a leaf spanning more than 2^32 keys (rare): written back as it is, finished by k_sort_lds behind us
-							const u32 slot = atomicAdd(handOnCnt, 1u);
-							if (slot < handOnCap) handOn[slot] = SortTask{t.start + (u64)first, (u32)size, (u32)depth};
-						}
-					}
-					finished = size;
-				}
-				else if (depth == 0)
-				{
-					wsort::wave_mem_fence();
-					if (lane == 0) { wsort::PtrAcc<KT, VP> acc{sK, sV}; fgsort::heap_sort_(acc, first, last); }
-					wsort::wave_mem_fence();
-					finished = size;
-				}
-				if (finished)
-				{
-					if (lane == 0) atomicSub(&ctl[2], finished);
-					break;
-				}
-				--depth;
-				const int cut = wsort::partition_stream(sK, sV, first, last);
-				int oa, ob;
-				if (cut - first < last - cut) { oa = cut; ob = last; last = cut; }
-				else { oa = first; ob = cut; first = cut; }
-				if (ob - oa < 2)
-				{
-					if (lane == 0 && ob > oa) atomicSub(&ctl[2], ob - oa);
-				}
-				else
-				{
-					int pushed = 0;
-					wsort::wave_mem_fence();
-					if (lane == 0 && lock())
-					{
-						const int top = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						if (top < SORT_MID_QCAP)
-						{
-							q[3 * top] = oa; q[3 * top + 1] = ob; q[3 * top + 2] = depth;
-							__hip_atomic_store(&ctl[0], top + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							pushed = 1;
-						}
-						unlock();
-					}
-					pushed = wsort::uni(pushed);
-					if (!pushed)
-					{
-						// np < SORT_MID_PRIV: the waiting halves of one wave shrink by half from entry to entry
-						if (lane == 0) { priv[3 * np] = oa; priv[3 * np + 1] = ob; priv[3 * np + 2] = depth; }
-						++np;
-					}
-				}
-				if (last - first < 2)		// the half that continues may be a single hit
-				{
-					if (lane == 0 && last > first) atomicSub(&ctl[2], last - first);
-					break;
-				}
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x == 0 && ctl[4]) atomicOr(errWord, (u32)ctl[4]);
-		for (int i = threadIdx.x; i < n; i += SORT_MID_WAVES * 64) { K[i] = sK[i]; V[i] = sV[i]; }
-		__syncthreads();
 	}
 }
 
@@ -1152,7 +884,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	const u64 bigCap = nHits / SORT_CAP + nSeg + 16;
 	c->dTmp32.reserve(std::max<u64>(2 * nHits + 2, 4 * c->hitCapHint + 16));	// the chaining stage wants 4 per hit of it: sized once
 	c->dSortTasks.reserve((size_t)smallCap * sizeof(SortTask));
-	c->dSortBig.reserve((size_t)(7 * bigCap) * sizeof(SortTask));
+	c->dSortBig.reserve((size_t)(6 * bigCap) * sizeof(SortTask));
 	c->dListCnt.reserve(4);
 	c->dSortCnt.reserve(4 * (SORT_MAX_LEVELS + 2) + 4);
 	SortTask* smallT = (SortTask*)c->dSortTasks.p;
@@ -1161,21 +893,10 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	SortTask* kids = bigB + bigCap;	// 2 * bigCap
 	SortTask* wideA = kids + 2 * bigCap;
 	SortTask* wideB = wideA + bigCap;
-	SortTask* midT = wideB + bigCap;
 	u32* levelCnt = c->dSortCnt.p;							// row l at levelCnt + 4 l
-	u32* smallCnt = c->dSortCnt.p + 4 * (SORT_MAX_LEVELS + 2);	// [0] small pieces, [1] mid pieces, [2] k_sort_mid's ticket
+	u32* smallCnt = c->dSortCnt.p + 4 * (SORT_MAX_LEVELS + 2);
 	const u32 streamMax = getenv("FG_SORT_STREAM_MAX") ? (u32)atoi(getenv("FG_SORT_STREAM_MAX")) : 8192u;
 	const u32 wideMin = getenv("FG_SORT_WIDE_MIN") ? (u32)atoi(getenv("FG_SORT_WIDE_MIN")) : 16384u;
-	// pieces of up to midMax hits leave the level loop for k_sort_mid (0: none do); bounded by the LDS of a CU.
-	// Off by default: measured on the bench workload the levels it replaces are bandwidth-bound at ~1 ms each and the
-	// leaves run at full occupancy in k_sort_lds, while the workgroup holds two blocks' worth of LDS per CU -- 22 ms
-	// against the 11 ms it takes over
-	u32 midMax = getenv("FG_SORT_MID_MAX") ? (u32)atoi(getenv("FG_SORT_MID_MAX")) : 0u;
-	{
-		const u32 fit = (u32)((160 * 1024 - sortMidLdsBytes(0, 0)) / MidBytes<KT>::perHit) & ~63u;
-		midMax = std::min(midMax & ~63u, fit);
-		if (midMax <= SORT_CAP) midMax = 0;
-	}
 	// Levels with many pieces of a LARGE chunk (>= 2^29 hits: a level's bytes take milliseconds, longer than the serial
 	// chain of its longest streamed piece) stream pieces of up to nHits / 8192 hits.  Measured (tools/many_ab.sh):
 	// dmel x 0.25, 1.5 G hits per chunk, sort levels 537 -> 431 ms per pass; on the bench workload (0.33 G hits, a
@@ -1183,21 +904,21 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 	const u32 manyMin = getenv("FG_SORT_MANY_MIN") ? (u32)atoi(getenv("FG_SORT_MANY_MIN")) : 4096u;
 	const u32 streamMany = getenv("FG_SORT_STREAM_MANY") ? (u32)atoi(getenv("FG_SORT_STREAM_MANY"))
 		: (nHits >= (1ULL << 29) ? (u32)std::min<u64>(std::max<u64>(nHits / 8192, streamMax), 262144) : streamMax);
-	const SortLists lists{nullptr, nullptr, smallT, midT, wideMin, midMax, smallCap, manyMin, std::max(streamMany, streamMax), streamMax};
+	const SortLists lists{smallT, wideMin, smallCap, manyMin, std::max(streamMany, streamMax), streamMax};
 	HIP_CHECK(hipMemsetAsync(c->dSortCnt.p, 0, c->dSortCnt.bytes(), s));
 	{ ScopedK t(c->timer, "k_sort_level");
 	  hipLaunchKernelGGL(k_sort_init, (nSeg + WG - 1) / WG, WG, 0, s, dSegOff, nSeg, lists, bigA, wideA, levelCnt, smallCnt); }
-	// counts of level `lvl` (and the small and mid pieces queued so far) to the host
-	u32 cnt[4] = {0, 0, 0, 0};		// big, small (total), wide, mid (total)
+	// counts of level `lvl` (and the small pieces queued so far) to the host
+	u32 cnt[3] = {0, 0, 0};		// big, small (total), wide
 	auto fetchCounts = [&](int lvl)
 	{
 		c->hScalar.reserve(8);
 		HIP_CHECK(hipMemcpyAsync(c->hScalar.p, levelCnt + 4 * lvl, 16, hipMemcpyDeviceToHost, s));
-		HIP_CHECK(hipMemcpyAsync((char*)c->hScalar.p + 16, smallCnt, 8, hipMemcpyDeviceToHost, s));
+		HIP_CHECK(hipMemcpyAsync((char*)c->hScalar.p + 16, smallCnt, 4, hipMemcpyDeviceToHost, s));
 		HIP_CHECK(hipStreamSynchronize(s));
-		u32 row[6];
-		memcpy(row, c->hScalar.p, 24);
-		cnt[0] = row[0]; cnt[2] = row[2]; cnt[1] = row[4]; cnt[3] = row[5];
+		u32 row[5];
+		memcpy(row, c->hScalar.p, 20);
+		cnt[0] = row[0]; cnt[2] = row[2]; cnt[1] = row[4];
 	};
 	fetchCounts(0);
 	static const bool trace = getenv("FG_SORT_TRACE") != nullptr;
@@ -1219,7 +940,7 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 		u64 ubBig = cnt[0], ubWide = cnt[2];
 		for (int b = 0; b < levelBatch && level < SORT_MAX_LEVELS; ++b)
 		{
-			if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks, %u small and %u mid pieces so far\n", level, cnt[0], cnt[2], cnt[1], cnt[3]);
+			if (trace) fprintf(stderr, "sort level %d: %u one-wave tasks, %u wide tasks, %u small pieces so far\n", level, cnt[0], cnt[2], cnt[1]);
 			ScopedK t(c->timer, trace ? levelNames[level < 31 ? level : 31] : "k_sort_level");
 			const u32* rowL = levelCnt + 4 * level;
 			u32* rowN = levelCnt + 4 * (level + 1);
@@ -1242,48 +963,13 @@ static void sortSegments(fg_ctx* c, const u64* dSegOff, u32 nSeg, KT* dK, u32* d
 		if (level >= SORT_MAX_LEVELS) throw FgError{FG_ERR_HIP, "internal: sort level budget exceeded"};
 		fetchCounts(level);
 	}
-	if (trace) fprintf(stderr, "sort: %d levels, %u small and %u mid pieces\n", level, cnt[1], cnt[3]);
 	if (cnt[1] > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
 	if (cnt[1])
 	{
 		ScopedK t(c->timer, "k_sort_lds");
 		hipLaunchKernelGGL(k_sort_lds<KT>, (cnt[1] + SORT_LDS_WAVES - 1) / SORT_LDS_WAVES, SORT_LDS_WAVES * 64, 0, s,
-						   smallT, 0u, cnt[1], (const u32*)nullptr, 0u, dK, dV, curBits, narrowMax, c->dTmp32.p, nHits);
+						   smallT, cnt[1], dK, dV, curBits, narrowMax, c->dTmp32.p, nHits);
 	}
-	if (cnt[3])
-	{
-		const size_t lds = (size_t)midMax * MidBytes<KT>::perHit;		// the piece; lists, stacks and counters are static LDS
-		static size_t ldsSet = 0;		// per instantiation
-		if (lds > ldsSet)
-		{
-			HIP_CHECK(hipFuncSetAttribute((const void*)k_sort_mid<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-			ldsSet = lds;
-		}
-		const unsigned perCu = (unsigned)std::max<size_t>(1, (160 * 1024) / sortMidLdsBytes(MidBytes<KT>::perHit, midMax));
-		{ ScopedK t(c->timer, "k_sort_mid");
-		  hipLaunchKernelGGL(k_sort_mid<KT>, (unsigned)std::min<u64>(cnt[3], 256ULL * perCu), SORT_MID_WAVES * 64, lds, s,
-							 midT, cnt[3], smallCnt + 2, midMax, dK, dV, curBits, narrowMax, smallT, smallCap, smallCnt, smallCnt + 3); }
-		// the kernel's error word comes back with the next counts the caller waits for (fgSortCheck)
-		c->hSortErr.reserve(1);
-		HIP_CHECK(hipMemcpyAsync(c->hSortErr.p, smallCnt + 3, 4, hipMemcpyDeviceToHost, s));
-		c->sortErrPending = true;
-		if (sizeof(KT) != 4)
-		{
-			// leaves k_sort_mid could not narrow to 32-bit keys sit behind the small pieces sorted above
-			{ ScopedK t(c->timer, "k_sort_lds");
-			  hipLaunchKernelGGL(k_sort_lds<KT>, 128, SORT_LDS_WAVES * 64, 0, s, smallT, cnt[1], 0u, (const u32*)smallCnt, smallCap,
-								 dK, dV, curBits, narrowMax, c->dTmp32.p, nHits); }
-			if (fetchScalar(c, smallCnt) > smallCap) throw FgError{FG_ERR_HIP, "internal: sort task queue overflow"};
-		}
-	}
-}
-
-// after a wait on the stream that follows a sort: did a workgroup of k_sort_mid give up?
-static void sortCheck(fg_ctx* c)
-{
-	if (!c->sortErrPending) return;
-	c->sortErrPending = false;
-	if (*c->hSortErr.p) throw FgError{FG_ERR_HIP, "internal: a workgroup of the hit sort stalled"};
 }
 
 void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nSeg)
@@ -1299,7 +985,6 @@ void fgDebugSortPairs(fg_ctx* c, u64* keys, u32* vals, const u64* segOff, u32 nS
 	HIP_CHECK(hipMemcpyAsync(keys, dK.p, n * 8, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipMemcpyAsync(vals, dV.p, n * 4, hipMemcpyDeviceToHost, s));
 	HIP_CHECK(hipStreamSynchronize(s));
-	sortCheck(c);
 }
 
 // seed collection's probe step with the probes partitioned by table region (see k_probe_emit): fills c->dProbe,
@@ -1461,7 +1146,6 @@ static void deviceSub(fg_ctx* c, const fg_detector_params* p, uint8_t forceLocal
 	{ ScopedK t(c->timer, "k_exscan");
 	  hipLaunchKernelGGL(k_exscan, 1, 1024, 0, s, c->dGroupCnt.p, c->dGroupOff.p, nq); }
 	const u64 nGroups = fetchScalar(c, c->dGroupOff.p + nq);
-	sortCheck(c);
 	if (nGroups >= 0xFFFFFFFFULL) throw FgError{FG_ERR_ARG, "too many target groups in one chunk"};
 	c->dGroupStart.reserve(nGroups + 1); c->dGroupQuery.reserve(nGroups + 1);
 	c->dGroupExt.reserve(nGroups + 1); c->dGroupFirstCur.reserve(nGroups + 1); c->dGroupLastCur.reserve(nGroups + 1);

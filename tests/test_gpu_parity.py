@@ -229,17 +229,15 @@ def _median3_killer(n):
     return a
 
 
-@pytest.mark.parametrize("stream_max", [None, 600, 10 ** 9, "mid1024", "mid8192", "many"])
+@pytest.mark.parametrize("stream_max", [None, 600, 10 ** 9, "many"])
 def test_device_sort_equals_std_sort(built, monkeypatch, stream_max):
     """k_sort_hits on its own: tie-heavy, patterned and adversarial inputs must come
-    out in exactly the permutation std::sort produces (heapsort fallback included).  Every tier and form of the
-    level loop: the streamed and the closed-form partition at any piece size, the in-LDS workgroup tier
-    (k_sort_mid, FG_SORT_MID_MAX) and the many-pieces rule of large chunks forced on at this size."""
+    out in exactly the permutation std::sort produces (heapsort fallback included).  Every form of the level
+    loop: the streamed and the closed-form partition at any piece size, and the many-pieces rule of large chunks
+    forced on at this size."""
     from flye_amd import gpu
     from oracle import oracle as O
-    if isinstance(stream_max, str) and stream_max.startswith("mid"):
-        monkeypatch.setenv("FG_SORT_MID_MAX", stream_max[3:])
-    elif stream_max == "many":
+    if stream_max == "many":
         monkeypatch.setenv("FG_SORT_MANY_MIN", "2")
         monkeypatch.setenv("FG_SORT_STREAM_MANY", "50000")
     elif stream_max is not None:      # which partition form the level kernel uses above the LDS piece size
@@ -888,11 +886,11 @@ def test_partitioned_probes_are_invisible(built, golden_cases, monkeypatch, name
     ctx.close()
 
 
-@pytest.mark.parametrize("name,env", [("raw_pb", {"FG_SORT_MID_MAX": "2048"}), ("hifi", {"FG_SORT_MID_MAX": "4096"}),
-                                      ("raw_ont_rc", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"})])
+@pytest.mark.parametrize("name,env", [("raw_ont_rc", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"}),
+                                      ("hifi", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"})])
 def test_sort_tiers_are_invisible(built, golden_cases, monkeypatch, name, env):
-    """The hit sort's optional tiers inside the overlap stage itself (32-bit keys): the in-LDS workgroup tier
-    k_sort_mid and the many-pieces streaming rule, forced on at golden-case size: same records."""
+    """The many-pieces streaming rule of the hit sort's levels (large chunks only by default), forced on at golden-case
+    size inside the overlap stage itself: same records."""
     case = golden_cases[name]
     rs = golden_reads(case)
     from flye_amd import config
@@ -904,8 +902,6 @@ def test_sort_tiers_are_invisible(built, golden_cases, monkeypatch, name, env):
     res = det.getSeqOverlapsBatch(case_queries(case, rs.n), forceLocal=case.get("force_local", False),
                                   maxOverlaps=case.get("max_overlaps", 0))
     assert res.lines() == golden_lines(name)
-    if "FG_SORT_MID_MAX" in env:
-        assert "k_sort_mid" in ctx.kernel_times()
     ctx.close()
 
 
