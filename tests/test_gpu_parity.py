@@ -887,7 +887,11 @@ def test_partitioned_probes_are_invisible(built, golden_cases, monkeypatch, name
 
 
 @pytest.mark.parametrize("name,env", [("raw_ont_rc", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"}),
-                                      ("hifi", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"})])
+                                      ("hifi", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000"}),
+                                      # the record forms of large inputs: packed 64-bit records, 64-bit keys + values
+                                      ("raw_pb", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000", "FG_FORCE_KEY64": "1"}),
+                                      ("hifi", {"FG_SORT_MANY_MIN": "2", "FG_SORT_STREAM_MANY": "100000", "FG_FORCE_KEY64": "1",
+                                                "FG_PACKED_KEYS": "0"})])
 def test_sort_tiers_are_invisible(built, golden_cases, monkeypatch, name, env):
     """The many-pieces streaming rule of the hit sort's levels (large chunks only by default), forced on at golden-case
     size inside the overlap stage itself: same records."""
