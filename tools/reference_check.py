@@ -46,9 +46,17 @@ with tempfile.TemporaryDirectory() as tmp:
     ov = os.path.join(tmp, "ovlp.txt")
     rs.write_fasta(fa)
     t0 = time.perf_counter()
+    # the reference's index build says nothing for minutes: a line a minute, so that the box's watchdog sees a live run
+    import threading
+    done = threading.Event()
+    def heartbeat():
+        while not done.wait(60.0):
+            print(f"  reference running, {time.perf_counter() - t0:.0f} s", flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
     info = O.run_ref(fa, params_string=config.params_string(preset), threads=threads, min_read_len=0,
                      min_overlap=config.DETECTOR_MIN_OVERLAP, query_limit=n_q, ovlp_out=ov)
     wall = time.perf_counter() - t0
+    done.set()
     same = bench.records_equal_ref_file(res.recs, ov)
 out = {"workload": name, "scale": scale, "reads": int(rs.n), "read_bp": int(rs.total_bases), "queries": int(n_q),
        "device_index_entries": int(st["index_entries"]), "device_records": int(len(res.recs)),
