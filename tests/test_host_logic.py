@@ -36,3 +36,28 @@ def test_synth_is_deterministic():
     assert not np.array_equal(a.length, c.length)
     sub = a.subset([0, 2])
     assert sub.n == 2 and sub.length[1] == a.length[2]
+
+
+def test_bench_byte_model_and_stage_attribution():
+    """bench.py's algorithmic bytes (16.25 + 44 m + 20 d B/bp): the kernels of a stage share the
+    stage's bytes, k_chain_small is credited with the DP elements of the groups it processed only, and the stage
+    figures add up to the whole formula."""
+    import bench
+    bp, m, d, ovl, d_small = 1e6, 1.5, 1.1, 0.008, 0.8
+    per = {k: bench.algorithmic_bytes(k, bp, m, d, ovl, d_small) for k in
+           ("k_probe", "k_fill", "k_sort_level", "k_sort_lds", "k_chain_dp", "k_chain_small", "k_group_prep")}
+    assert per["k_probe"] == (0.25 + 16.0) * bp
+    assert per["k_fill"] == m * 20.0 * bp
+    assert per["k_sort_level"] == per["k_sort_lds"] == m * 24.0 * bp
+    assert per["k_chain_dp"] == (d * 20.0 + 44.0 * ovl) * bp
+    assert per["k_chain_small"] == d_small * 20.0 * bp < per["k_chain_dp"]
+    assert per["k_group_prep"] == 0.0
+    assert bench.algorithmic_bytes("k_chain_small", bp, m, d, ovl) == per["k_chain_dp"]     # no counter: the stage's bytes
+    times = {"k_probe": (1e-3, 1), "k_fill": (1e-3, 1), "k_exscan": (1e-4, 3), "k_sort_level": (2e-3, 20), "k_sort_lds": (1e-3, 1),
+             "k_chain_small": (2e-3, 1), "k_group_prep": (1e-3, 2), "k_prim_gather": (1e-4, 1), "host:shim": (5e-3, 1)}
+    st = bench.stage_rooflines(times, bp, m, d, ovl, None)
+    assert set(st) == {"seed_collect", "hit_sort", "chain"}
+    total = sum(v["algorithmic_bytes"] for v in st.values())
+    assert abs(total - (16.25 + 44.0 * m + 20.0 * d + 44.0 * ovl) * bp) <= 3
+    assert st["hit_sort"]["kernels"] == ["k_sort_lds", "k_sort_level"] and abs(st["hit_sort"]["exclusive_ms"] - 3.0) < 1e-9
+    assert "traffic" not in st["chain"]
