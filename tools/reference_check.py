@@ -12,14 +12,14 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import bench
 from flye_amd import config, gpu, workloads
 from oracle import oracle as O
-import bench
 
 name = sys.argv[1]
 scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 n_q = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
-threads = int(sys.argv[4]) if len(sys.argv) > 4 else (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8)
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else bench.effective_cpus()
 if name == "ecoli_pb50":
     rs, min_ovlp, preset = workloads.ecoli_pb50(scale=scale)
 elif name == "dmel_ont30":
