@@ -152,9 +152,13 @@ def _view(ptr: int, n: int, cuda_dev, typestr="<i8"):
 def _all_reduce_dev(t, on_device: bool):
     """sum over the ranks, in place, of a device tensor: RCCL on the tensor itself, or (gloo rehearsal) through a
     host copy"""
+    import torch
     import torch.distributed as td
     if on_device:
         td.all_reduce(t)
+        # the library reads the array on ITS stream next (fg_index_batch_select): the collective has to be complete on
+        # the host's clock, not just ordered on torch's stream
+        torch.cuda.synchronize()
     else:
         h = t.cpu()
         td.all_reduce(h)

@@ -145,7 +145,9 @@ int fg_index_finish(fg_ctx* ctx, const uint64_t* total_sums, struct fg_index_sta
  *                   positions each, default 2^28: the selection's scratch is bounded by that, not by the read set);
  *   batch_freq      KmerCounter::getFreq of every k-mer position of batch b as far as THIS context counted it (0
  *                   outside its range) into a device array (*d_freq, *n uint32): summed over the ranks in place
- *                   (all-reduce) it is the complete array; on one GPU it already is;
+ *                   (all-reduce) it is the complete array; on one GPU it already is.  The array is complete when
+ *                   the call returns; the caller's reduction must itself be COMPLETE (host-synchronised: the library
+ *                   works on its own streams) before batch_select is called;
  *   batch_select    yieldFrequentKmers (vertex_index.cpp:316-358) over the batch's reads from that array;
  *   selection_done  releases the batch scratch; hist[] as fg_index_begin_solid gives it.
  * fg_index_begin_solid = count_slice(0, FG_INDEX_BINS) + {batch_freq, batch_select} per batch + selection_done.
