@@ -760,6 +760,7 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 			int32_t maxScore = 0, maxId = 0;
 			const int32_t curNext = M[i].cur, extNext = M[i].ext;
 			int32_t scanned = 0;
+			int32_t validBefore = 0; bool brokeClose = false;	// FO_STATS6: valid candidates met before the closing one
 			for (int32_t j = i - 1; j >= 0; --j)
 			{
 				++scanned;
@@ -775,13 +776,29 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 					{
 						maxScore = nextScore;
 						maxId = j;
-						if (jumpDiv == 0 && curNext - curPrev < k) break;
+						if (jumpDiv == 0 && curNext - curPrev < k) { brokeClose = true; break; }
 					}
+					++validBefore;
 				}
 				if (extSorted && extNext - extPrev > P.max_jump) break;
 				if (!extSorted && curNext - curPrev > P.max_jump) break;
 			}
 			counters[4] += scanned; counters[5] += scanned > 16; counters[6] += scanned > 64;
+			if (getenv("FO_STATS6"))
+			{
+				// how many elements end their scan at a same-diagonal predecessor closer than k with NO valid candidate in
+				// between (then the outcome is known without the scan), by how far back that predecessor is
+				static std::atomic<unsigned long long> F[8];	// [0] elements, [1] at i-1, [2] at i-2, [3] i-3, [4] i-4, [5] 5..8, [6] further
+				F[0] += 1;
+				if (brokeClose && validBefore == 0)
+					F[scanned == 1 ? 1 : scanned == 2 ? 2 : scanned == 3 ? 3 : scanned == 4 ? 4 : scanned <= 8 ? 5 : 6] += 1;
+				if ((F[0] & 0x3FFFFF) == 0)
+				{
+					fprintf(stderr, "closing predecessor with nothing valid in between:");
+					for (int b = 1; b < 7; ++b) fprintf(stderr, " %.3f", (double)F[b] / F[0]);
+					fprintf(stderr, " of %llu elements (at i-1, i-2, i-3, i-4, 5..8 back, further)\n", (unsigned long long)F[0]);
+				}
+			}
 			if (getenv("FO_STATS3"))
 			{
 				static std::atomic<unsigned long long> L[12];	// elements by scan length 1..10, >10; [11] = count
