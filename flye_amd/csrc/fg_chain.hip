@@ -379,6 +379,11 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 	// away that the candidate is out of range and beyond the window by the ordinary tests
 	const i32 FAR = -(1 << 30);
 	i32 pc = FAR, pe = FAR, ps = 0;		// previous tile
+	// Upper bound for the deep look-backs: no candidate j scores more than score[j] + k (matchScore <= k, gapCost >= 0),
+	// so once (the largest score among ALL elements up to j) + k <= the running best, nothing further back can replace
+	// it -- the reference's scan would walk on through the window (HiFi data: ~270 candidates per head, 4-5 steps of
+	// 64) without ever updating.  Lane b holds the largest score of tiles 0 .. b (first 64 tiles; beyond: no bound).
+	i32 pmv = 0x7fffffff, pmRun = I32_MIN;
 	i32 ntc = lane < n ? (i32)cur[lane] : 0, nte = lane < n ? (i32)ext[lane] : 0;
 	asm volatile("" : "+v"(ntc), "+v"(nte));	// waited for here, so that no wait for them is left inside the loop (see its end)
 	for (i32 tb0 = 0; tb0 < n; tb0 += 64)
@@ -441,6 +446,10 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 			}
 			for (i32 jb = i - 65; jb >= 0 && !done; jb -= 64)
 			{
+				{
+					const int blk = jb >> 6;		// every candidate of this and the following steps lies in tiles 0 .. blk
+					if (blk < 64 && __builtin_amdgcn_readlane(pmv, blk) <= maxScore - k) break;
+				}
 				// deeper: lane = scan position; the previous DP_RING elements of finished tiles from LDS,
 				// anything older from memory (stored by this wave)
 				const i32 j = jb - lane;
@@ -485,6 +494,12 @@ __device__ __forceinline__ void dp_group(const int k, const i32 maxJump, const i
 			if (!WHOLE) { ringC[(tb0 + lane) & (DP_RING - 1)] = tc; ringE[(tb0 + lane) & (DP_RING - 1)] = te; ringS[(tb0 + lane) & (DP_RING - 1)] = ts; }
 		}
 		if (WHOLE) wsort::wave_mem_fence();		// the next tile's deep look-backs read these scores from LDS
+		{
+			const i32 tileMax = __builtin_amdgcn_readlane(wave_incl_max(valid ? ts : I32_MIN), 63);
+			pmRun = max(pmRun, tileMax);
+			const int t = tb0 >> 6;
+			if (t < 64) pmv = lane == t ? pmRun : pmv;
+		}
 		pc = tc; pe = te; ps = ts;
 	}
 }
