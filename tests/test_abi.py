@@ -117,3 +117,18 @@ def test_context_creation_leaves_libc_rand_stream_alone(built):
             "libc.srand(1); c = gpu.Context(17, 0); print(libc.rand())") % ROOT
     out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True)
     assert int(out.stdout.split()[-1]) == 1804289383     # glibc: first value of the stream seeded with 1
+
+
+def test_every_device_primitive_is_ours(built):
+    """north_star asks for hand-written kernels: the library's code objects hold no rocPRIM / hipCUB / Thrust kernel
+    (their template instantiations would carry those namespaces in the kernel names embedded in the .so), and the
+    sources include none of those headers."""
+    so = os.path.join(ROOT, "flye_amd", "lib", "libflyegpu.so")
+    blob = open(so, "rb").read().lower()
+    for lib_name in (b"rocprim", b"hipcub", b"thrust"):
+        assert lib_name not in blob, f"{lib_name.decode()} kernels inside libflyegpu.so"
+    src = os.path.join(ROOT, "flye_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h", ".cpp")):
+            text = open(os.path.join(src, f)).read()
+            assert not re.search(r"#include\s*<(rocprim|hipcub|thrust)/", text), f
