@@ -987,6 +987,19 @@ void seqOverlaps(const Ctx& c, const fg_detector_params& P, u32 recIdx, bool for
 	}
 	for (auto& w : wnd) if (w.range > 0) stats.push_back(w.div);
 	counters[7] += tieInQuery;
+	if (getenv("FO_STATS7"))
+	{
+		// queries whose surviving groups hold no tied key: their result would be the same under ANY sort, even one
+		// restricted to the hits of the surviving groups
+		static std::atomic<unsigned long long> Q[6];	// queries, hits, tie-free queries, their hits; no tie at all: queries, hits
+		bool anyTie = false;
+		for (size_t t = 1; t < nh && !anyTie; ++t) anyTie = S.hits[t].extId == S.hits[t - 1].extId && S.hits[t].cur == S.hits[t - 1].cur;
+		Q[0] += 1; Q[1] += nh; if (!tieInQuery) { Q[2] += 1; Q[3] += nh; } if (!anyTie) { Q[4] += 1; Q[5] += nh; }
+		if ((Q[0] & 0x3FF) == 0)
+			fprintf(stderr, "queries %llu (%llu hits): no tie inside a group that reaches the DP in %llu (%llu hits); no tie at all in %llu (%llu hits)\n",
+					(unsigned long long)Q[0], (unsigned long long)Q[1], (unsigned long long)Q[2], (unsigned long long)Q[3],
+					(unsigned long long)Q[4], (unsigned long long)Q[5]);
+	}
 }
 
 } // namespace
